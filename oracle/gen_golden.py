@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""
+Generate golden input/output vectors by running the REAL reference solvers
+(``/root/reference/crt1d/solvers``) -- runs only in the build container, never on the GPU box.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--out tests/golden] [--only g1,g3]
+
+``import crt1d`` itself fails here with an ordinary ``ModuleNotFoundError`` (xarray is not
+installed), so an empty parent package is registered and only the NumPy/SciPy-only submodules are
+imported (``crt1d.solvers``, ``crt1d.leaf_angle``, ``crt1d.leaf_area``) -- SURVEY.md section 8(c).
+``crt1d.cases``/``crt1d.data`` need xarray; the default-case *inputs* are rebuilt from the
+reference's packaged CSV files following ``cases.py:15-58`` and ``data/__init__.py:23-35,90-157``.
+
+Fixtures (``.npz``, data only):
+
+g1_default   default canopy (60 levels x 107 SPCTRAL2 bands), all 8 schemes
+g2_bonan     inputs of the reference's tests/test_n79.py:13-44; n79 with '9sky' and 'quad'
+g3_uniform   12 synthetic columns x 10 bands x 60 levels (equal dLAI), 7 schemes (+ 4s tol=1e-11)
+g4_ragged    12 synthetic columns x 10 bands x 40 levels, NON-uniform dLAI (exposes the quirks)
+g5_4s_tight  default case, 4s with solve_bvp tol 1e-11 (the reference's stock tol is 1e-6)
+g7_options   mu_s in {0.501, 0.33998}; G_fn in {spherical, horizontal, vertical, ellipsoidal x in {0.5,1,2}, bonan}
+"""
+
+import argparse
+import importlib
+import os
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import scipy
+
+REF = Path("/root/reference")
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+
+
+def import_reference():
+    pkg = types.ModuleType("crt1d")
+    pkg.__path__ = [str(REF / "crt1d")]
+    sys.modules["crt1d"] = pkg
+    la = importlib.import_module("crt1d.leaf_angle")
+    lar = importlib.import_module("crt1d.leaf_area")
+    sol = importlib.import_module("crt1d.solvers")
+    return la, lar, sol
+
+
+META = dict(scipy=scipy.__version__, numpy=np.__version__, generator="oracle/gen_golden.py")
+
+SCHEMES = ["2s", "4s", "bf", "bl", "g77", "n79", "zq", "zq_pa"]
+
+
+def run_scheme(sol, name, p, **opts):
+    """Call reference solve_<name> with exactly its declared args (as Model.run does, model.py:305-310)."""
+    sd = sol.AVAILABLE_SCHEMES[name]
+    args = {k: p[k] for k in sd["args"]}
+    return sd["solver"](**args, **opts)
+
+
+def tight_bvp(tol=1e-11):
+    """Context: make the reference's solve_bvp calls use a tighter tolerance (oracle process only)."""
+    import scipy.integrate as si
+
+    class _Ctx:
+        def __enter__(self):
+            self.orig = si.solve_bvp
+
+            def wrapped(fun, bc, x, y, **kw):
+                kw["tol"] = tol
+                kw.setdefault("max_nodes", 200000)
+                res = self.orig(fun, bc, x, y, **kw)
+                assert res.status == 0, res.message
+                return res
+
+            si.solve_bvp = wrapped
+
+        def __exit__(self, *a):
+            si.solve_bvp = self.orig
+
+    return _Ctx()
+
+
+def default_case_inputs(la, lar, nlayers=60):
+    """cases.py:15-58 with data/__init__.py loaders restated on the packaged CSVs."""
+    d = REF / "crt1d" / "data"
+    res = lar.distribute_lai_beta(20.0, 4.0, nlayers)
+    # ideal leaf, midpoint version (data/__init__.py:90-113)
+    wl, t, r = np.loadtxt(d / "ideal-green-leaf_SPCTRAL2-wavelengths.csv", delimiter=",", skiprows=1, unpack=True)
+    t[t == 0] = 1e-10
+    r[r == 0] = 1e-10
+    wl_m, t_m, r_m = (wl[:-1] + wl[1:]) / 2, (t[:-1] + t[1:]) / 2, (r[:-1] + r[1:]) / 2
+    # SPCTRAL2 default spectrum, midpoint version (data/__init__.py:116-147)
+    wl0, SI_dr0, SI_df0 = np.loadtxt(d / "SPCTRAL2_xls_default-spectrum.csv", delimiter=",", skiprows=1, unpack=True)
+    dwl = np.diff(wl0)
+    wl_sp = wl0[:-1] + 0.5 * dwl
+    I_dr = (SI_dr0[:-1] + SI_dr0[1:]) / 2 * dwl
+    I_df = (SI_df0[:-1] + SI_df0[1:]) / 2 * dwl
+    assert np.allclose(wl_m, wl_sp)
+    # soil (data/__init__.py:23-35)
+    rs = np.ones_like(wl_m)
+    rs[wl_m <= 0.7] = 0.1100
+    rs[wl_m > 0.7] = 0.2250
+    ok = ~(np.isnan(t_m) | np.isnan(r_m) | np.isnan(I_dr) | np.isnan(I_df))  # .dropna(dim="wl") cases.py:25
+    mla = 57
+    x = la.mla_to_x_approx(mla)
+    G_fn = lambda psi_: la.G_ellipsoidal_approx(psi_, x)  # noqa: E731
+    psi = np.deg2rad(20)
+    p = dict(
+        lai=res.lai, z=res.z, mla=mla, clump=1.0, orient=x, G_fn=G_fn, psi=psi,
+        leaf_t=t_m[ok], leaf_r=r_m[ok], soil_r=rs[ok], I_dr0_all=I_dr[ok], I_df0_all=I_df[ok],
+        wl=wl_m[ok], dwl=dwl[ok],
+    )
+    p["K_b_fn"] = lambda psi_: p["G_fn"](psi_) / np.cos(psi_)  # model.py:291
+    return p
+
+
+def save(out, name, **arrays):
+    arrays = {k: np.asarray(v) for k, v in arrays.items()}
+    arrays["meta"] = np.array(repr(META))
+    path = out / f"{name}.npz"
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({path.stat().st_size/1e3:.0f} kB)")
+
+
+def flatten(prefix, sol_dict):
+    return {f"{prefix}__{k}": v for k, v in sol_dict.items()}
+
+
+def g1(la, lar, sol, out):
+    p = default_case_inputs(la, lar)
+    arrays = dict(
+        psi=p["psi"], lai=p["lai"], mla=p["mla"], x=p["orient"], leaf_t=p["leaf_t"], leaf_r=p["leaf_r"],
+        soil_r=p["soil_r"], I_dr0_all=p["I_dr0_all"], I_df0_all=p["I_df0_all"], wl=p["wl"], dwl=p["dwl"],
+        clump=p["clump"],
+    )
+    for s in SCHEMES:
+        arrays.update(flatten(s, run_scheme(sol, s, p)))
+        print("  g1", s)
+    save(out, "g1_default", **arrays)
+    return p
+
+
+def g5(la, lar, sol, out, p):
+    with tight_bvp():
+        r = run_scheme(sol, "4s", p)
+    save(out, "g5_4s_tight", **flatten("4s_tol1e-11", r))
+
+
+def g2(la, lar, sol, out):
+    lap = lar.distribute_lai_beta_bonan(20, 6, 61)
+    p = dict(
+        lai=lap.lai, z=lap.z, psi=30 * (np.pi / 180),
+        leaf_r=np.r_[0.1, 0.45], leaf_t=np.r_[0.05, 0.25], I_dr0_all=np.r_[0.8, 0.8], I_df0_all=np.r_[0.2, 0.2],
+        soil_r=np.r_[0.1, 0.2], wl=np.r_[0.55, 1.6], dwl=np.r_[0.3, 1.8], clump=1.0, G_fn=la.G_spherical,
+    )
+    p["K_b_fn"] = lambda psi_: p["G_fn"](psi_) / np.cos(psi_)
+    arrays = {k: p[k] for k in ("lai", "z", "psi", "leaf_r", "leaf_t", "I_dr0_all", "I_df0_all", "soil_r", "wl", "dwl")}
+    arrays.update(flatten("n79_9sky", run_scheme(sol, "n79", p, tau_d_method="9sky")))
+    arrays.update(flatten("n79_quad", run_scheme(sol, "n79", p, tau_d_method="quad")))
+    save(out, "g2_bonan", **arrays)
+
+
+def synth_case(la, sol, out, name, ncol, nb, nz, uniform, schemes, with_tight_4s):
+    from crt1d_amd.synth import make_columns
+
+    cols = make_columns(ncol, nb, nz, seed=1234 if uniform else 4321, uniform_dlai=uniform)
+    arrays = {k: cols[k] for k in ("psi", "lai", "mla", "g_kind", "g_param", "leaf_r", "leaf_t", "soil_r", "I_dr0", "I_df0", "wle")}
+    results = {}
+    for c in range(ncol):
+        x = cols["g_param"][c]
+        p = dict(
+            psi=float(cols["psi"][c]), lai=cols["lai"][c].copy(), mla=float(cols["mla"][c]), clump=1.0,
+            leaf_r=cols["leaf_r"][c], leaf_t=cols["leaf_t"][c], soil_r=cols["soil_r"][c],
+            I_dr0_all=cols["I_dr0"][c], I_df0_all=cols["I_df0"][c],
+            G_fn=lambda psi_, x=x: la.G_ellipsoidal_approx(psi_, x),
+        )
+        p["K_b_fn"] = lambda psi_, p=p: p["G_fn"](psi_) / np.cos(psi_)
+        for s in schemes:
+            r = run_scheme(sol, s, p)
+            for k, v in r.items():
+                results.setdefault(f"{s}__{k}", []).append(v)
+        if with_tight_4s:
+            with tight_bvp():
+                r = run_scheme(sol, "4s", p)
+            for k, v in r.items():
+                results.setdefault(f"4s_tol1e-11__{k}", []).append(v)
+        print(f"  {name} column {c+1}/{ncol}")
+    arrays.update({k: np.stack(v) for k, v in results.items()})
+    save(out, name, **arrays)
+
+
+def g7(la, lar, sol, out):
+    """Option sweep on a small case: 20 levels x 6 bands, one column per G function."""
+    rng = np.random.default_rng(77)
+    nz, nb = 20, 6
+    lai = np.linspace(3.2, 0, nz)
+    base = dict(
+        psi=np.deg2rad(37.0), lai=lai, mla=45.0, clump=1.0,
+        leaf_r=rng.uniform(0.05, 0.5, nb), leaf_t=rng.uniform(0.03, 0.4, nb), soil_r=rng.uniform(0.05, 0.4, nb),
+        I_dr0_all=rng.uniform(0, 10, nb), I_df0_all=rng.uniform(0, 5, nb),
+    )
+    arrays = {k: base[k] for k in ("psi", "lai", "mla", "leaf_r", "leaf_t", "soil_r", "I_dr0_all", "I_df0_all")}
+    gfuns = {
+        "spherical": (la.G_spherical, 1, 0.0),
+        "horizontal": (la.G_horizontal, 0, 0.0),
+        "vertical": (la.G_vertical, 2, 0.0),
+        "ellipsoidal_x0.5": (lambda p: la.G_ellipsoidal(p, 0.5), 3, 0.5),
+        "ellipsoidal_x1": (lambda p: la.G_ellipsoidal(p, 1), 3, 1.0),
+        "ellipsoidal_x2": (lambda p: la.G_ellipsoidal(p, 2.0), 3, 2.0),
+        "ellipsoidal_approx_x2": (lambda p: la.G_ellipsoidal_approx(p, 2.0), 4, 2.0),
+        "bonan_xl0.25": (lambda p: la.G_ellipsoidal_approx_bonan(p, 0.25), 5, 0.25),
+        "bonan_xl-0.9": (lambda p: la.G_ellipsoidal_approx_bonan(p, -0.9), 5, -0.9),
+    }
+    names, kinds, params = [], [], []
+    for gname, (gf, kind, param) in gfuns.items():
+        p = dict(base, G_fn=gf)
+        p["K_b_fn"] = lambda psi_, p=p: p["G_fn"](psi_) / np.cos(psi_)
+        names.append(gname)
+        kinds.append(kind)
+        params.append(param)
+        for s in ("2s", "bl", "g77", "n79", "zq"):
+            if gname == "horizontal" and s in ("bl", "n79", "zq"):
+                pass  # K_b_fn = 1 exactly; quad still fine
+            arrays.update(flatten(f"{gname}__{s}", run_scheme(sol, s, p)))
+        arrays.update(flatten(f"{gname}__n79_9sky", run_scheme(sol, "n79", p, tau_d_method="9sky")))
+        for mu_s in (0.501, 0.33998):
+            with tight_bvp():
+                arrays.update(flatten(f"{gname}__4s_mus{mu_s}_tol1e-11", run_scheme(sol, "4s", p, mu_s=mu_s)))
+        print("  g7", gname)
+    arrays["g_names"] = np.array(names)
+    arrays["g_kind"] = np.array(kinds, dtype=np.int32)
+    arrays["g_param"] = np.array(params)
+    save(out, "g7_options", **arrays)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=str(REPO / "tests" / "golden"))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    out = Path(a.out)
+    out.mkdir(parents=True, exist_ok=True)
+    only = set(a.only.split(",")) if a.only else None
+    want = lambda k: only is None or k in only  # noqa: E731
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    import warnings
+
+    warnings.simplefilter("ignore")
+    la, lar, sol = import_reference()
+    p = None
+    if want("g1") or want("g5"):
+        p = default_case_inputs(la, lar)
+    if want("g1"):
+        g1(la, lar, sol, out)
+    if want("g5"):
+        g5(la, lar, sol, out, p)
+    if want("g2"):
+        g2(la, lar, sol, out)
+    if want("g3"):
+        synth_case(la, sol, out, "g3_uniform", 12, 10, 60, True, ["2s", "4s", "bf", "bl", "g77", "n79", "zq"], True)
+    if want("g4"):
+        synth_case(la, sol, out, "g4_ragged", 12, 10, 40, False, ["2s", "4s", "bf", "bl", "g77", "n79", "zq"], True)
+    if want("g7"):
+        g7(la, lar, sol, out)
+
+
+if __name__ == "__main__":
+    main()
