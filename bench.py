@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""
+bench.py -- the hot path of BASELINE.json measured on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scheme 2s] [--ncol 10000] [--nb 300] [--nz 60]
+
+Workload (N = 1): BASELINE.json configs[1] -- ``solve_2s`` batched over 1e4 synthetic profiles x 300 bands x
+60 levels, fp64, inputs resident in HBM before the timed region.  One *step* = one pass of the hot path over
+the batch = column-precompute kernel K0 + the solve kernel, through the C ABI (``crt_hip_2s_f64``).
+N > 1 (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``): the (column x band) grid is
+sharded by column blocks, every rank solves its own ``--ncol`` columns (weak scaling), no data-path collective
+(independent units); only the timing is reduced (max over ranks).
+
+Prints ONE JSON line on rank 0.  ``roofline``: the dominant kernel (the solve kernel, launched alone with
+CRT_FLAG_SKIP_PRECOMPUTE between two HIP events on its own stream) against the 8 TB/s HBM3E peak;
+algorithmic bytes per solve as SURVEY section 8(d) / BASELINE.md section 3.  ``cpu_baseline``: the NumPy oracle
+(a port of the reference algorithm; the reference itself is pure Python and cannot travel to the GPU box)
+timed on this box's host cores on a bounded sample of the same workload, rank 0, N = 1 only.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+# algorithmic bytes per (column x band) solve: s * [n_in + n_full * nz + n_mid * (nz - 1)], s = 8 (fp64)
+# (each compulsory byte once: per-band inputs read, full profiles written)
+N_IO = {  # scheme: (n_in, n_full, n_mid)
+    "2s": (5, 4, 0), "4s": (5, 4, 0), "bl": (4, 4, 0), "g77": (5, 7, 0), "bf": (5, 7, 0), "n79": (5, 4, 2), "zq": (5, 7, 0),
+}
+KERNEL_NAMES = {"2s": "k_2s", "4s": "k_4s", "bl": "k_bl", "g77": "k_g77", "bf": "k_g77", "n79": "k_n79", "zq": "k_zq"}
+
+
+def bytes_per_solve(scheme, nz):
+    n_in, n_full, n_mid = N_IO[scheme]
+    return 8 * (n_in + n_full * nz + n_mid * (nz - 1))
+
+
+def cpu_baseline(scheme, nb, nz, budget_s=15.0):
+    """Oracle (NumPy port of the reference algorithm) on the host: solves/s on 1 core, bounded sample."""
+    import numpy as np
+
+    from crt1d_amd import synth
+    from oracle import crt_oracle as O
+
+    chunk = 50
+    d = synth.make_columns(chunk, nb, nz, seed=99)
+    oc = O.Columns(d["psi"], d["lai"], mla=d["mla"], g_kind=d["g_kind"], g_param=d["g_param"])
+    kw = dict(I_dr0=d["I_dr0"], I_df0=d["I_df0"], leaf_r=d["leaf_r"], leaf_t=d["leaf_t"], soil_r=d["soil_r"])
+    if scheme == "bl":
+        kw.pop("soil_r")
+    fn = O.SOLVERS[scheme]
+    fn(oc, **kw)  # warm
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        fn(oc, **kw)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 400:
+            break
+    # reference-shaped variant: one column per call (the reference has no batching), a few columns only
+    t1 = time.perf_counter()
+    ncs = 0
+    for c in range(min(chunk, 20)):
+        o1 = O.Columns(d["psi"][c:c + 1], d["lai"][c:c + 1], mla=d["mla"][c:c + 1], g_kind=d["g_kind"][c:c + 1],
+                       g_param=d["g_param"][c:c + 1])
+        fn(o1, **{k: v[c:c + 1] for k, v in kw.items()})
+        ncs += 1
+    per_col = (time.perf_counter() - t1) / ncs
+    return {
+        "value": n * chunk * nb / el,
+        "unit": "solves/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"oracle.solve_{scheme} (NumPy, vectorised over {chunk}-column chunks) on {n * chunk} columns x {nb} bands x "
+                  f"{nz} levels in {el:.1f} s; one-column-per-call (reference-shaped) rate {nb / per_col:.3g} solves/s; "
+                  f"host has {os.cpu_count()} logical cores, 1 used",
+    }
+
+
+def load_pmc_traffic(scheme):
+    """HBM bytes per launch of the solve kernel from the committed rocprofv3 --pmc summary, if any."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            d = json.load(f)
+        e = d.get(scheme)
+        return None if e is None else e.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scheme", default="2s", choices=sorted(N_IO))
+    ap.add_argument("--ncol", type=int, default=10000, help="columns PER GPU")
+    ap.add_argument("--nb", type=int, default=300)
+    ap.add_argument("--nz", type=int, default=60)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit(f"--gpus {a.gpus} needs: python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+
+    from crt1d_amd import _lib, batched, synth
+
+    scheme, ncol, nb, nz = a.scheme, a.ncol, a.nb, a.nz
+    # column shard of this rank: its own seed -> distinct columns of one global grid
+    d = synth.make_columns(ncol, nb, nz, seed=1234 + rank)
+    cols = batched.Columns.from_host(d, dev)
+    bands = batched.Bands.from_host(d, dev)
+    plan = batched.Plan(scheme, cols, bands)
+    stream = torch.cuda.current_stream(dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        plan()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        plan()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    solves_per_step = ncol * nb * world
+    value = solves_per_step * a.steps / el
+
+    # ---- dominant kernel alone, HIP events on the stream it is launched on ----
+    reps = max(20, a.steps)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for _ in range(3):
+        plan(flags=_lib.FLAG_SKIP_PRECOMPUTE)
+    torch.cuda.synchronize(dev)
+    for e0, e1 in evs:
+        e0.record(stream)
+        plan(stream, flags=_lib.FLAG_SKIP_PRECOMPUTE)
+        e1.record(stream)
+    torch.cuda.synchronize(dev)
+    kt = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    k_ms_avg = sum(kt) / len(kt)
+    k_ms_med = kt[len(kt) // 2]
+    # K0 alone
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(10):
+        plan(stream, flags=_lib.FLAG_PRECOMPUTE_ONLY)
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    k0_ms = e0.elapsed_time(e1) / 10
+
+    bps = bytes_per_solve(scheme, nz)
+    alg_bytes = bps * ncol * nb  # per launch, this GPU
+    achieved = alg_bytes / (k_ms_avg * 1e-3) / 1e9
+
+    # ---- measured HBM ceilings from the same run (streaming fill / copy of 4 GiB) ----
+    lib = _lib.load()
+    n = 1 << 29  # doubles = 4 GiB
+    buf = torch.empty(n, dtype=torch.float64, device=dev)
+    src = torch.empty(n, dtype=torch.float64, device=dev).fill_(1.0)
+
+    def timed(fn, nrep=5):
+        fn()
+        torch.cuda.synchronize(dev)
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record(stream)
+        for _ in range(nrep):
+            fn()
+        a1.record(stream)
+        torch.cuda.synchronize(dev)
+        return a0.elapsed_time(a1) / nrep * 1e-3
+
+    t_fill = timed(lambda: lib.crt_hip_probe_fill_f64(buf.data_ptr(), n, 0.5, stream.cuda_stream))
+    t_copy = timed(lambda: lib.crt_hip_probe_copy_f64(buf.data_ptr(), src.data_ptr(), n, stream.cuda_stream))
+    fill_gbs = 8 * n / t_fill / 1e9
+    copy_gbs = 2 * 8 * n / t_copy / 1e9
+    del buf, src
+
+    out = {
+        "metric": "(column x band) solves/sec at 60 layers" if nz == 60 else f"(column x band) solves/sec at {nz} layers",
+        "value": value,
+        "unit": "solves/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": el / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"solve_{scheme} batched: {ncol} synthetic profiles x {nb} bands x {nz} levels per GPU, fp64 "
+                        f"(BASELINE.json configs[1] shape)" if (scheme, ncol, nb, nz) == ("2s", 10000, 300, 60) else
+                        f"solve_{scheme} batched: {ncol} synthetic profiles x {nb} bands x {nz} levels per GPU, fp64",
+            "scheme": scheme, "ncol_per_gpu": ncol, "nb": nb, "nz": nz, "partition": "column blocks, no collective",
+            "step": "K0 column precompute + solve kernel via crt_hip_%s_f64" % scheme,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": KERNEL_NAMES[scheme],
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": load_pmc_traffic(scheme),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "bytes_per_solve": bps,
+            "kernel_ms_avg": k_ms_avg,
+            "kernel_ms_median": k_ms_med,
+            "k0_ms": k0_ms,
+            "measured_fill_GBs": fill_gbs,
+            "measured_copy_GBs": copy_gbs,
+            "frac_of_measured_fill": achieved / fill_gbs,
+        },
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(scheme, nb, nz, a.cpu_budget)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+"""
+ctypes binding of ``libcrt1d_hip.so`` (C ABI declared in ``include/crt1d_hip.h``).
+
+There is deliberately NO fallback: if the HIP library is missing every solver raises.
+"""
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrt1d_hip.so")
+
+# enum crt_scheme
+SCHEME_IDS = {"2s": 0, "4s": 1, "n79": 2, "zq": 3, "bl": 4, "g77": 5, "bf": 6}
+TAU_D_METHODS = {"quad": 0, "9sky": 1}
+NQ_TAU, NQ_G4, NQ_9SKY = 96, 32, 9
+NQ = NQ_TAU + NQ_G4 + NQ_9SKY
+
+FLAG_SKIP_PRECOMPUTE = 1
+FLAG_PRECOMPUTE_ONLY = 2
+
+CRT_OK = 0
+CRT_ERR_BAD_ARG = -1
+CRT_ERR_WORKSPACE = -2
+CRT_ERR_UNSUPPORTED = -3
+CRT_ERR_LAUNCH = -4
+CRT_ERR_SHAPE = -5
+
+_vp = ctypes.c_void_p
+
+
+class CrtColumns(ctypes.Structure):
+    _fields_ = [
+        ("ncol", ctypes.c_int32),
+        ("nz", ctypes.c_int32),
+        ("psi", _vp),
+        ("lai", _vp),
+        ("mla", _vp),
+        ("g_kind", _vp),
+        ("g_param", _vp),
+        ("g_at_psi", _vp),
+        ("g_table", _vp),
+    ]
+
+
+class CrtBands(ctypes.Structure):
+    _fields_ = [
+        ("nb", ctypes.c_int32),
+        ("col_stride", ctypes.c_int64),
+        ("I_dr0", _vp),
+        ("I_df0", _vp),
+        ("leaf_r", _vp),
+        ("leaf_t", _vp),
+        ("soil_r", _vp),
+    ]
+
+
+class CrtOptions(ctypes.Structure):
+    _fields_ = [("mu_s", ctypes.c_double), ("tau_d_method", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+class CrtOutputs(ctypes.Structure):
+    _fields_ = [(k, _vp) for k in ("I_dr", "I_df_d", "I_df_u", "F", "x0", "x1", "x2")]
+
+
+EXPORTS = [
+    "crt_hip_abi_version",
+    "crt_hip_strerror",
+    "crt_hip_workspace_bytes",
+    "crt_hip_quad_nodes",
+    "crt_hip_solve_f64",
+    "crt_hip_2s_f64",
+    "crt_hip_4s_f64",
+    "crt_hip_n79_f64",
+    "crt_hip_zq_f64",
+    "crt_hip_bl_f64",
+    "crt_hip_g77_f64",
+    "crt_hip_bf_f64",
+    "crt_hip_absorb_bandsum_f64",
+    "crt_hip_probe_fill_f64",
+    "crt_hip_probe_copy_f64",
+]
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises :class:`HipLibraryMissing` if not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: the HIP kernels are not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C crt1d_amd/csrc`). "
+            "crt1d_amd has no CPU fallback."
+        )
+    # torch first: it brings its own libamdhip64.so.7; ours must bind to the same runtime instance
+    import torch  # noqa: F401
+
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.crt_hip_abi_version.restype = ctypes.c_int
+    lib.crt_hip_strerror.restype = ctypes.c_char_p
+    lib.crt_hip_strerror.argtypes = [ctypes.c_int]
+    lib.crt_hip_workspace_bytes.restype = ctypes.c_size_t
+    lib.crt_hip_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int32, ctypes.c_int32]
+    lib.crt_hip_quad_nodes.restype = ctypes.c_int
+    lib.crt_hip_quad_nodes.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    solve_args = [
+        ctypes.POINTER(CrtColumns),
+        ctypes.POINTER(CrtBands),
+        ctypes.POINTER(CrtOptions),
+        ctypes.POINTER(CrtOutputs),
+        _vp,
+        ctypes.c_size_t,
+        _vp,
+    ]
+    lib.crt_hip_solve_f64.restype = ctypes.c_int
+    lib.crt_hip_solve_f64.argtypes = [ctypes.c_int] + solve_args
+    for s in SCHEME_IDS:
+        f = getattr(lib, f"crt_hip_{s}_f64")
+        f.restype = ctypes.c_int
+        f.argtypes = solve_args
+    lib.crt_hip_absorb_bandsum_f64.restype = ctypes.c_int
+    lib.crt_hip_absorb_bandsum_f64.argtypes = [
+        ctypes.POINTER(CrtColumns), ctypes.POINTER(CrtBands), _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp,
+    ]
+    lib.crt_hip_probe_fill_f64.restype = ctypes.c_int
+    lib.crt_hip_probe_fill_f64.argtypes = [_vp, ctypes.c_size_t, ctypes.c_double, _vp]
+    lib.crt_hip_probe_copy_f64.restype = ctypes.c_int
+    lib.crt_hip_probe_copy_f64.argtypes = [_vp, _vp, ctypes.c_size_t, _vp]
+    if lib.crt_hip_abi_version() != 1:
+        raise HipLibraryMissing(f"{LIB_PATH}: ABI version mismatch, rebuild")
+    _lib = lib
+    return lib
+
+
+def strerror(status):
+    return load().crt_hip_strerror(int(status)).decode()
+
+
+def check(status, what):
+    """Translate a C-ABI status into the reference's exception conventions
+    (AssertionError for shape/orientation, ValueError for bad options)."""
+    if status == CRT_OK:
+        return
+    msg = f"{what}: {strerror(status)} (status {status})"
+    if status == CRT_ERR_SHAPE:
+        raise AssertionError(msg)
+    if status == CRT_ERR_BAD_ARG:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def quad_nodes(mu_s=0.501):
+    """Zenith angles (radians) at which a sampled ``G_fn`` table must be given; (NQ,) float64."""
+    import numpy as np
+
+    buf = (ctypes.c_double * NQ)()
+    check(load().crt_hip_quad_nodes(float(mu_s), buf), "crt_hip_quad_nodes")
+    return np.frombuffer(buf, dtype=np.float64).copy()

@@ -1,0 +1,260 @@
+"""
+Batched (column x band) canopy-RT solves on PyTorch-ROCm tensors.
+
+PyTorch is plumbing here: device memory, streams and (in :mod:`crt1d_amd.dist`)
+``torch.distributed``.  All arithmetic happens in the hand-written gfx950 kernels of
+``libcrt1d_hip.so``, reached through the C ABI with ``tensor.data_ptr()``.
+
+Shapes: ``ncol`` columns, ``nb`` bands, ``nz`` interface levels.  Outputs are
+``(ncol, nz, nb)`` (``(ncol, nz-1, nb)`` for n79's per-leaf-area absorption), bands contiguous --
+the reference's ``(nz, nb)`` solver outputs (e.g. ``_solve_2s.py:45-49``) stacked over columns.
+"""
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+SCHEMES = tuple(_lib.SCHEME_IDS)
+
+# output keys per scheme, in crt_outputs slot order (I_dr, I_df_d, I_df_u, F, x0, x1, x2)
+OUT_KEYS = {
+    "2s": ("I_dr", "I_df_d", "I_df_u", "F"),  # _solve_2s.py:158-163
+    "4s": ("I_dr", "I_df_d", "I_df_u", "F"),  # _solve_4s.py:293
+    "bl": ("I_dr", "I_df_d", "I_df_u", "F"),  # _solve_bl.py:93
+    "n79": ("I_dr", "I_df_d", "I_df_u", "F", "aI_lsl", "aI_lsh"),  # _solve_n79.py:157-164
+    "zq": ("I_dr", "I_df_d", "I_df_u", "F", "I_df_d_ss", "I_df_u_ss", "F_ss"),  # _solve_zq.py:221-229
+    "g77": ("I_dr", "I_df_d", "I_df_u", "F", "aI_lsl", "aI_lsh", "aI_l"),  # _solve_g77.py:127-135
+    "bf": ("I_dr", "I_df_d", "I_df_u", "F", "aI_lsl", "aI_lsh", "aI_l"),  # _solve_bf.py:144-153 (+ rho_c host-side)
+}
+_MID_KEYS = {"n79": ("aI_lsl", "aI_lsh")}  # (ncol, nz-1, nb)
+
+
+def _f64(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.dtype != torch.float64:
+        raise TypeError(f"{name} must be float64, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (got {t.device}); crt1d_amd has no CPU path")
+    return t.contiguous()
+
+
+@dataclass
+class Columns:
+    """Device-resident per-column canopy geometry (what one reference ``Model`` holds)."""
+
+    psi: torch.Tensor  # (ncol,)
+    lai: torch.Tensor  # (ncol, nz), index 0 = ground
+    g_kind: torch.Tensor  # (ncol,) int32, crt1d_amd.leaf_angle kind ids
+    g_param: torch.Tensor  # (ncol,)
+    mla: Optional[torch.Tensor] = None  # (ncol,) degrees; 2s only
+    g_at_psi: Optional[torch.Tensor] = None  # (ncol,)  G_TABLE columns
+    g_table: Optional[torch.Tensor] = None  # (ncol, NQ) G_TABLE columns
+
+    def __post_init__(self):
+        self.psi = _f64(self.psi, "psi")
+        self.lai = _f64(self.lai, "lai")
+        if self.lai.ndim != 2 or self.psi.shape != (self.lai.shape[0],):
+            raise ValueError("lai must be (ncol, nz) and psi (ncol,)")
+        self.g_param = _f64(self.g_param, "g_param")
+        if self.g_kind.dtype != torch.int32 or not self.g_kind.is_cuda:
+            raise TypeError("g_kind must be a CUDA int32 tensor")
+        self.g_kind = self.g_kind.contiguous()
+        for name in ("mla", "g_at_psi"):
+            v = getattr(self, name)
+            if v is not None:
+                v = _f64(v, name)
+                if v.shape != self.psi.shape:
+                    raise ValueError(f"{name} must be (ncol,)")
+                setattr(self, name, v)
+        if self.g_table is not None:
+            self.g_table = _f64(self.g_table, "g_table")
+            if self.g_table.shape != (self.ncol, _lib.NQ):
+                raise ValueError(f"g_table must be (ncol, {_lib.NQ})")
+
+    @property
+    def ncol(self):
+        return self.lai.shape[0]
+
+    @property
+    def nz(self):
+        return self.lai.shape[1]
+
+    @property
+    def device(self):
+        return self.lai.device
+
+    def slice(self, lo, hi):
+        """Columns [lo, hi) as a view (used by the column-sharded multi-GPU path)."""
+        g = lambda t: None if t is None else t[lo:hi]  # noqa: E731
+        return Columns(self.psi[lo:hi], self.lai[lo:hi], self.g_kind[lo:hi], self.g_param[lo:hi], g(self.mla),
+                       g(self.g_at_psi), g(self.g_table))
+
+    def c_struct(self):
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        return _lib.CrtColumns(self.ncol, self.nz, p(self.psi), p(self.lai), p(self.mla), p(self.g_kind), p(self.g_param),
+                               p(self.g_at_psi), p(self.g_table))
+
+    @classmethod
+    def from_host(cls, d, device="cuda"):
+        """From a dict of NumPy arrays (e.g. :func:`crt1d_amd.synth.make_columns`)."""
+        t = lambda k: None if d.get(k) is None else torch.as_tensor(d[k]).to(device)  # noqa: E731
+        return cls(t("psi"), t("lai"), t("g_kind"), t("g_param"), t("mla"), t("g_at_psi"), t("g_table"))
+
+
+@dataclass
+class Bands:
+    """Per-(column, band) spectra; each tensor is (ncol, nb), or (nb,)/(1, nb) to share one
+    spectrum over all columns (the reference's (n_wl,) plugin inputs)."""
+
+    I_dr0: torch.Tensor
+    I_df0: torch.Tensor
+    leaf_r: torch.Tensor
+    leaf_t: torch.Tensor
+    soil_r: Optional[torch.Tensor] = None
+
+    def __post_init__(self):
+        shape = None
+        for name in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r"):
+            v = getattr(self, name)
+            if v is None:
+                continue
+            v = _f64(v, name)
+            if v.ndim == 1:
+                v = v[None, :]
+            if v.ndim != 2:
+                raise ValueError(f"{name} must be (ncol, nb) or (nb,)")
+            if shape is None:
+                shape = v.shape
+            elif v.shape != shape:
+                raise ValueError("all band arrays must have the same shape")
+            setattr(self, name, v)
+        self._shape = shape
+
+    @property
+    def nb(self):
+        return self._shape[1]
+
+    def col_stride(self, ncol):
+        if self._shape[0] == 1 and ncol != 1:
+            return 0
+        if self._shape[0] != ncol:
+            raise ValueError(f"band arrays have {self._shape[0]} rows but there are {ncol} columns")
+        return self.nb
+
+    def slice(self, lo, hi):
+        if self._shape[0] == 1:
+            return self
+        g = lambda t: None if t is None else t[lo:hi]  # noqa: E731
+        return Bands(self.I_dr0[lo:hi], self.I_df0[lo:hi], self.leaf_r[lo:hi], self.leaf_t[lo:hi], g(self.soil_r))
+
+    def band_slice(self, lo, hi):
+        """Bands [lo, hi) of every column (band-sharded multi-GPU path); copies to keep rows contiguous."""
+        g = lambda t: None if t is None else t[:, lo:hi].contiguous()  # noqa: E731
+        return Bands(g(self.I_dr0), g(self.I_df0), g(self.leaf_r), g(self.leaf_t), g(self.soil_r))
+
+    def c_struct(self, ncol):
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        return _lib.CrtBands(self.nb, self.col_stride(ncol), p(self.I_dr0), p(self.I_df0), p(self.leaf_r), p(self.leaf_t),
+                             p(self.soil_r))
+
+    @classmethod
+    def from_host(cls, d, device="cuda"):
+        t = lambda k: None if d.get(k) is None else torch.as_tensor(d[k]).to(device)  # noqa: E731
+        return cls(t("I_dr0"), t("I_df0"), t("leaf_r"), t("leaf_t"), t("soil_r"))
+
+
+def workspace_bytes(scheme, ncol, nz):
+    return int(_lib.load().crt_hip_workspace_bytes(_lib.SCHEME_IDS[scheme], ncol, nz))
+
+
+def alloc_outputs(scheme, ncol, nz, nb, device):
+    out = {}
+    for k in OUT_KEYS[scheme]:
+        n = nz - 1 if k in _MID_KEYS.get(scheme, ()) else nz
+        out[k] = torch.empty((ncol, n, nb), dtype=torch.float64, device=device)
+    return out
+
+
+class Plan:
+    """Pre-validated launch of one scheme on fixed buffers: ``plan()`` enqueues K0 + the solve kernel
+    on the current stream with no allocation and no host synchronisation (bench / steady-state use)."""
+
+    def __init__(self, scheme, cols: Columns, bands: Bands, *, mu_s=0.501, tau_d_method="quad", out=None, workspace=None):
+        if scheme not in _lib.SCHEME_IDS:
+            raise ValueError(f"unknown scheme {scheme!r}; valid: {', '.join(SCHEMES)}")
+        if tau_d_method not in _lib.TAU_D_METHODS:
+            raise ValueError("invalid `method`. Valid options are 'quad' and '9sky'.")  # common.py:78
+        self.lib = _lib.load()
+        self.scheme = scheme
+        self.cols, self.bands = cols, bands
+        ncol, nz, nb = cols.ncol, cols.nz, bands.nb
+        if scheme == "2s" and cols.mla is None:
+            raise ValueError("solve_2s needs `mla`")
+        if scheme != "bl" and bands.soil_r is None:
+            raise ValueError(f"solve_{scheme} needs `soil_r`")
+        self.out = alloc_outputs(scheme, ncol, nz, nb, cols.device) if out is None else out
+        need = workspace_bytes(scheme, ncol, nz)
+        if workspace is None:
+            workspace = torch.empty(need, dtype=torch.uint8, device=cols.device)
+        elif workspace.numel() * workspace.element_size() < need:
+            raise ValueError("workspace too small")
+        self.workspace = workspace
+        self._c = cols.c_struct()
+        self._b = bands.c_struct(ncol)
+        self._o = _lib.CrtOptions(float(mu_s), _lib.TAU_D_METHODS[tau_d_method], 0)
+        ptrs = [self.out[k].data_ptr() for k in OUT_KEYS[scheme]]
+        ptrs += [None] * (7 - len(ptrs))
+        self._out = _lib.CrtOutputs(*ptrs)
+        self._fn = getattr(self.lib, f"crt_hip_{scheme}_f64")
+        self._wsb = workspace.numel() * workspace.element_size()
+
+    def __call__(self, stream=None, *, flags=0):
+        """Enqueue on ``stream`` (default: torch's current stream).  ``flags``: ``_lib.FLAG_SKIP_PRECOMPUTE`` reuses
+        the column records already in the workspace (same geometry, new spectra); ``_lib.FLAG_PRECOMPUTE_ONLY``
+        runs only the column precompute."""
+        s = torch.cuda.current_stream(self.cols.device) if stream is None else stream
+        self._o.flags = int(flags)
+        st = self._fn(ctypes.byref(self._c), ctypes.byref(self._b), ctypes.byref(self._o), ctypes.byref(self._out),
+                      self.workspace.data_ptr(), self._wsb, s.cuda_stream)
+        _lib.check(st, f"crt_hip_{self.scheme}_f64")
+        return self.out
+
+
+def solve(scheme, cols: Columns, bands: Bands, *, mu_s=0.501, tau_d_method="quad", out=None, workspace=None):
+    """Run ``scheme`` over all (column, band) pairs; returns a dict of ``(ncol, nz, nb)`` CUDA tensors.
+
+    Asynchronous on the current stream, like any torch op.
+    """
+    with torch.cuda.device(cols.device):
+        return Plan(scheme, cols, bands, mu_s=mu_s, tau_d_method=tau_d_method, out=out, workspace=workspace)()
+
+
+def absorb_bandsum(cols: Columns, bands: Bands, sol, band_w):
+    """Layer absorption (``model.py:573-647``) reduced over bands with weights ``band_w (ngroup, nb)``
+    (``diagnostics.py:39-108``).  Returns ``aI, aI_sl, aI_sh`` ``(ncol, nz-1, ngroup)`` and the
+    energy-balance terms ``totals (ncol, ngroup, 4)`` = incoming, reflected, transmitted, soil-reflected."""
+    lib = _lib.load()
+    band_w = _f64(band_w, "band_w")
+    if band_w.ndim == 1:
+        band_w = band_w[None, :]
+    ng = band_w.shape[0]
+    ncol, nz = cols.ncol, cols.nz
+    dev = cols.device
+    aI = torch.empty((ncol, nz - 1, ng), dtype=torch.float64, device=dev)
+    aI_sl = torch.empty_like(aI)
+    aI_sh = torch.empty_like(aI)
+    totals = torch.empty((ncol, ng, 4), dtype=torch.float64, device=dev)
+    c, b = cols.c_struct(), bands.c_struct(ncol)
+    with torch.cuda.device(dev):
+        st = lib.crt_hip_absorb_bandsum_f64(
+            ctypes.byref(c), ctypes.byref(b), sol["I_dr"].data_ptr(), sol["I_df_d"].data_ptr(), sol["I_df_u"].data_ptr(),
+            band_w.data_ptr(), ng, aI.data_ptr(), aI_sl.data_ptr(), aI_sh.data_ptr(), totals.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream,
+        )
+    _lib.check(st, "crt_hip_absorb_bandsum_f64")
+    return {"aI": aI, "aI_sl": aI_sl, "aI_sh": aI_sh, "totals": totals}

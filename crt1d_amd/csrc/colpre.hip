@@ -1,0 +1,291 @@
+// K0: per-column precompute for the batched canopy-RT solvers (gfx950).
+//
+// Everything the reference computes once per `solve_*` call before its band loop -- K_b, mu_bar,
+// the G integrals, tau_d of every layer/level, exp(-K_b lai) -- is band-independent, so it is
+// computed once per column here (one 128-thread workgroup per column) and written as a small
+// record into the caller's workspace; the solve kernels stage it into LDS.
+//
+// The reference evaluates its integrals with adaptive QUADPACK (scipy.integrate.quad) over
+// arbitrary Python callables.  On device the integrals use FIXED nodes:
+//   * tau_d(L) = 2 int_0^{pi/2} exp(-K_b(psi) L) sin cos dpsi   (common.py:30-37)
+//     mu_bar   =   int_0^{pi/2} cos sin / G(psi) dpsi           (_solve_2s.py:32)
+//       6 panels x 16-point Gauss-Legendre on psi in [0, pi/2], panel widths shrinking by 4x toward
+//       pi/2 where exp(-G L / cos psi) has its essential singularity: <= 3e-13 relative for
+//       L in [1e-3, 20] and every leaf-angle class (the reference's own quad error is up to ~3e-8).
+//   * G_int_1 = int_0^{mu_s} G(acos m) dm,  G_int_2 = int_{mu_s}^1   (_solve_4s.py:148-149)
+//       16-point Gauss-Legendre each, in psi (dm = -sin psi dpsi).
+//   * '9sky': the reference's own 9 fixed angles                 (common.py:40-53)
+// A CRT_G_TABLE column brings G sampled at exactly these nodes (crt_hip_quad_nodes).
+#include <math.h>
+
+#include <mutex>
+
+#include "crt_internal.hpp"
+
+namespace crt {
+
+namespace {
+
+constexpr int NQT = CRT_NQ_TAU;
+constexpr int NQG = CRT_NQ_G4;
+constexpr int NPAN = 6;
+constexpr int NGL = 16;
+constexpr double PAN_RATIO = 0.25;
+static_assert(NPAN * NGL == NQT, "tau_d rule size");
+static_assert(2 * NGL == NQG, "4s rule size");
+
+struct QuadConst {
+  double psi[NQT], cs[NQT], sn[NQT];
+  double w[NQT];     // plain weights in psi
+  double w2sc[NQT];  // 2 w sin cos  (tau_d weights)
+  double gx[NGL], gw[NGL];
+  double cs9[CRT_NQ_9SKY], sn9[CRT_NQ_9SKY], sc9[CRT_NQ_9SKY];
+};
+
+__constant__ QuadConst qc;
+QuadConst h_qc;
+std::once_flag h_once;
+bool dev_inited[64] = {};
+std::mutex dev_mu;
+
+// Gauss-Legendre nodes/weights on [-1, 1] by Newton iteration on P_n
+void gauss_legendre(int n, double* x, double* w) {
+  for (int i = 0; i < n; ++i) {
+    double z = cos(M_PI * (i + 0.75) / (n + 0.5));
+    double pp = 0;
+    for (int it = 0; it < 100; ++it) {
+      double p1 = 1.0, p2 = 0.0;
+      for (int j = 1; j <= n; ++j) {
+        double p3 = p2;
+        p2 = p1;
+        p1 = ((2.0 * j - 1.0) * z * p2 - (j - 1.0) * p3) / j;
+      }
+      pp = n * (z * p1 - p2) / (z * z - 1.0);
+      double dz = p1 / pp;
+      z -= dz;
+      if (fabs(dz) < 1e-16) break;
+    }
+    // ascending order
+    x[n - 1 - i] = z;
+    w[n - 1 - i] = 2.0 / ((1.0 - z * z) * pp * pp);
+  }
+}
+
+void build_host_tables() {
+  gauss_legendre(NGL, h_qc.gx, h_qc.gw);
+  const double T = M_PI / 2;
+  // panel edges in t = pi/2 - psi: 0, T r^(NPAN-1), ..., T r, T
+  double edge[NPAN + 1];
+  edge[0] = 0.0;
+  for (int k = 1; k <= NPAN; ++k) edge[k] = T * pow(PAN_RATIO, NPAN - k);
+  int q = 0;
+  for (int k = 0; k < NPAN; ++k) {
+    const double a = edge[k], b = edge[k + 1];
+    for (int i = 0; i < NGL; ++i, ++q) {
+      const double t = a + (h_qc.gx[i] + 1.0) * (b - a) / 2;
+      const double psi = T - t;
+      h_qc.psi[q] = psi;
+      // cos(pi/2 - t) = sin t: keeps full relative accuracy next to pi/2
+      h_qc.cs[q] = sin(t);
+      h_qc.sn[q] = cos(t);
+      h_qc.w[q] = h_qc.gw[i] * (b - a) / 2;
+      h_qc.w2sc[q] = 2.0 * h_qc.w[q] * h_qc.sn[q] * h_qc.cs[q];
+    }
+  }
+  for (int i = 0; i < CRT_NQ_9SKY; ++i) {
+    const double psi = (5.0 + 10.0 * i) * (M_PI / 180.0);  // math.radians(sza), common.py:46-48
+    h_qc.cs9[i] = cos(psi);
+    h_qc.sn9[i] = sin(psi);
+    h_qc.sc9[i] = sin(psi) * cos(psi);
+  }
+}
+
+// 4s nodes: interval 0 = psi in [acos(mu_s), pi/2] (m in [0, mu_s]), interval 1 = [0, acos(mu_s)]
+__host__ __device__ inline void g4_interval(double mu_s, int iv, double& lo, double& hi) {
+  const double ps = acos(mu_s);
+  if (iv == 0) {
+    lo = ps;
+    hi = 1.57079632679489661923;
+  } else {
+    lo = 0.0;
+    hi = ps;
+  }
+}
+
+constexpr int K0_BLOCK = 128;
+
+__device__ inline double tau_d_quad(const double* kq, double L) {
+  double s = 0.0;
+  for (int q = 0; q < NQT; ++q) s += qc.w2sc[q] * exp(-kq[q] * L);
+  return s;
+}
+
+__device__ inline double tau_d_9sky(const double* k9, double L) {
+  double s = 0.0;
+  for (int i = 0; i < CRT_NQ_9SKY; ++i) s += exp(-k9[i] * L) * qc.sc9[i];
+  return s * (2.0 * 0.17453292519943295);  // * 2 radians(10), common.py:51
+}
+
+__global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
+  __shared__ double kq[NQT];    // K_b(psi_q) = G/cos at the tau_d nodes
+  __shared__ double pmb[NQT];   // mu_bar partial sums
+  __shared__ double pg[NQG];    // G-integral partial sums
+  __shared__ double k9[CRT_NQ_9SKY];
+  __shared__ double sh_kb;
+
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int nz = a.nz;
+  const int kind = a.g_kind[c];
+  const double param = a.g_param ? a.g_param[c] : 0.0;
+  const double* tab = (kind == CRT_G_TABLE) ? a.g_table + (long long)c * CRT_NQ : nullptr;
+  const double* lai = a.lai + (long long)c * nz;
+  const int reclen = rec_len(a.scheme, nz);
+  double* rec = a.ws + (long long)c * reclen;
+
+  for (int q = tid; q < NQT; q += K0_BLOCK) {
+    const double g = tab ? tab[q] : G_closed(kind, param, qc.cs[q], qc.sn[q]);
+    kq[q] = g / qc.cs[q];
+    pmb[q] = qc.w[q] * qc.cs[q] * qc.sn[q] / g;
+  }
+  if (a.scheme == CRT_SCHEME_4S && tid < NQG) {
+    const int iv = tid / NGL, i = tid % NGL;
+    double lo, hi;
+    g4_interval(a.mu_s, iv, lo, hi);
+    const double p = lo + (qc.gx[i] + 1.0) * (hi - lo) / 2;
+    const double g = tab ? tab[NQT + tid] : G_closed(kind, param, cos(p), sin(p));
+    pg[tid] = qc.gw[i] * (hi - lo) / 2 * g * sin(p);
+  }
+  if (tid < CRT_NQ_9SKY) {
+    const double g = tab ? tab[NQT + NQG + tid] : G_closed(kind, param, qc.cs9[tid], qc.sn9[tid]);
+    k9[tid] = g / qc.cs9[tid];
+  }
+  __syncthreads();
+
+  if (tid == 0) {
+    const double psi = a.psi[c];
+    const double cs = cos(psi), sn = sin(psi);
+    const double G = tab ? a.g_at_psi[c] : G_closed(kind, param, cs, sn);
+    const double Kb = G / cs;
+    double hdr[REC_HDR];
+    for (int i = 0; i < REC_HDR; ++i) hdr[i] = 0.0;
+    hdr[S_KB] = Kb;
+    hdr[S_MU] = cs;
+    hdr[S_G] = G;
+    hdr[S_INVMU] = 1.0 / cs;
+    hdr[S_LT] = lai[0];
+    if (a.scheme == CRT_SCHEME_2S) {
+      double s = 0.0;
+      for (int q = 0; q < NQT; ++q) s += pmb[q];  // fixed order: bitwise reproducible
+      hdr[S_MUBAR] = s;
+      const double cm = cos(a.mla[c] * (M_PI / 180.0));
+      hdr[S_COS2] = cm * cm;
+    }
+    if (a.scheme == CRT_SCHEME_4S) {
+      double s0 = 0.0, s1 = 0.0;
+      for (int i = 0; i < NGL; ++i) {
+        s0 += pg[i];
+        s1 += pg[NGL + i];
+      }
+      hdr[S_GINT1] = s0;
+      hdr[S_GINT2] = s1;
+    }
+    if (a.scheme == CRT_SCHEME_ZQ) {
+      // dlai_mean = |mean(diff(lai)[diff(lai) != 0])|   _solve_zq.py:30,50
+      double s = 0.0;
+      int n = 0;
+      for (int j = 0; j + 1 < nz; ++j) {
+        const double d = lai[j + 1] - lai[j];
+        if (d != 0.0) {
+          s += d;
+          ++n;
+        }
+      }
+      const double dlm = fabs(s / n);
+      hdr[S_DLM] = dlm;
+      hdr[S_TAUI] = tau_d_quad(kq, dlm);  // _solve_zq.py:51 (always 'quad')
+      hdr[S_TPSI] = exp(-Kb * dlm);       // :52
+    }
+    for (int i = 0; i < REC_HDR; ++i) rec[i] = hdr[i];
+    sh_kb = Kb;
+  }
+  __syncthreads();
+  const double Kb = sh_kb;
+
+  double* v = rec + REC_HDR;
+  for (int j = tid; j < nz; j += K0_BLOCK) {
+    const double L = lai[j];
+    const double ekl = exp(-Kb * L);
+    switch (a.scheme) {
+      case CRT_SCHEME_ZQ:
+        v[j] = ekl;
+        break;
+      case CRT_SCHEME_BL:
+        v[j] = L;
+        v[nz + j] = ekl;
+        v[2 * nz + j] = tau_d_quad(kq, L);  // _solve_bl.py:35-37
+        break;
+      case CRT_SCHEME_N79: {
+        v[j] = ekl;  // tbcum  _solve_n79.py:46
+        double tb = 0, td = 0, fs = 0, isl = 0, ish = 0;
+        if (j + 1 < nz) {
+          const double Ln = lai[j + 1];
+          const double dl = L - Ln;                                             // :40
+          tb = exp(-Kb * dl);                                                   // :45
+          td = (a.tau_d_method == CRT_TAU_D_9SKY) ? tau_d_9sky(k9, dl) : tau_d_quad(kq, dl);  // :53
+          fs = exp(-Kb * ((L + Ln) / 2));                                       // :57-58
+          isl = 1.0 / (fs * dl);                                                // :154
+          ish = 1.0 / ((1.0 - fs) * dl);                                        // :155
+        }
+        v[nz + j] = tb;
+        v[2 * nz + j] = td;
+        v[3 * nz + j] = fs;
+        v[4 * nz + j] = isl;
+        v[5 * nz + j] = ish;
+        break;
+      }
+      default:  // 2s, 4s, g77, bf
+        v[j] = L;
+        v[nz + j] = ekl;
+        break;
+    }
+  }
+}
+
+}  // namespace
+
+void host_quad_nodes(double mu_s, double* psi_nodes) {
+  std::call_once(h_once, build_host_tables);
+  for (int q = 0; q < NQT; ++q) psi_nodes[q] = h_qc.psi[q];
+  for (int t = 0; t < NQG; ++t) {
+    double lo, hi;
+    g4_interval(mu_s, t / NGL, lo, hi);
+    psi_nodes[NQT + t] = lo + (h_qc.gx[t % NGL] + 1.0) * (hi - lo) / 2;
+  }
+  for (int i = 0; i < CRT_NQ_9SKY; ++i) psi_nodes[NQT + NQG + i] = (5.0 + 10.0 * i) * (M_PI / 180.0);
+}
+
+int init_quadrature(hipStream_t s) {
+  std::call_once(h_once, build_host_tables);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return CRT_ERR_LAUNCH;
+  if (dev < 0 || dev >= 64) return CRT_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lk(dev_mu);
+  if (!dev_inited[dev]) {
+    // first call on this device only; not capturable into a hipGraph (documented in DESIGN.md)
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(qc), &h_qc, sizeof(QuadConst), 0, hipMemcpyHostToDevice, s) != hipSuccess)
+      return CRT_ERR_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return CRT_ERR_LAUNCH;
+    dev_inited[dev] = true;
+  }
+  return CRT_OK;
+}
+
+int launch_colpre(const ColArgs& a, hipStream_t s) {
+  int st = init_quadrature(s);
+  if (st != CRT_OK) return st;
+  hipLaunchKernelGGL(k_colpre, dim3(a.ncol), dim3(K0_BLOCK), 0, s, a);
+  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+}
+
+}  // namespace crt

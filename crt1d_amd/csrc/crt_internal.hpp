@@ -1,0 +1,189 @@
+// Internal declarations shared by the gfx950 kernels of libcrt1d_hip.so.  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "crt1d_hip.h"
+
+namespace crt {
+
+// ------------------------------------------------------------------------------------------
+// Per-column record written by the column-precompute kernel (K0) into the caller's workspace
+// and staged into LDS by every solve kernel: a 16-double header + nvec vectors of nz doubles.
+//
+//   header: band-independent scalars the reference computes before its band loop
+//   vectors (by scheme):
+//     2s, 4s, g77, bf : lai, ekl = exp(-K_b lai)
+//     bl              : lai, ekl, tau_d(lai_j)                       (_solve_bl.py:31-37)
+//     n79             : tbcum = ekl, tb, td, fracsun, 1/(fracsun dlai), 1/(fracsha dlai)
+//                                                                     (_solve_n79.py:40-59)
+//     zq              : ekl                                           (_solve_zq.py:130)
+enum RecScalar {
+  S_KB = 0,     // K_b = G(psi)/cos(psi)              model.py:291-293
+  S_MU = 1,     // cos(psi)
+  S_G = 2,      // G(psi)
+  S_MUBAR = 3,  // int cos sin / G                     _solve_2s.py:32
+  S_GINT1 = 4,  // int_0^{mu_s} G(acos m) dm           _solve_4s.py:148
+  S_GINT2 = 5,  // int_{mu_s}^1                        _solve_4s.py:149
+  S_DLM = 6,    // |mean(dlai[dlai != 0])|             _solve_zq.py:50
+  S_TAUI = 7,   // tau_d(dlai_mean)                    _solve_zq.py:51
+  S_TPSI = 8,   // exp(-K_b dlai_mean)                 _solve_zq.py:52
+  S_COS2 = 9,   // cos^2(radians(mla))                 _solve_2s.py:28,68
+  S_LT = 10,    // lai[0], total LAI
+  S_INVMU = 11, // 1/cos(psi)
+  REC_HDR = 16
+};
+
+__host__ __device__ inline int rec_nvec(int scheme) {
+  switch (scheme) {
+    case CRT_SCHEME_BL: return 3;
+    case CRT_SCHEME_N79: return 6;
+    case CRT_SCHEME_ZQ: return 1;
+    default: return 2;
+  }
+}
+__host__ __device__ inline int rec_len(int scheme, int nz) { return REC_HDR + rec_nvec(scheme) * nz; }
+
+// ------------------------------------------------------------------------------------------
+// kernel argument blocks (passed by value)
+struct ColArgs {
+  int ncol, nz, scheme, tau_d_method;
+  double mu_s;
+  const double* psi;
+  const double* lai;
+  const double* mla;
+  const int32_t* g_kind;
+  const double* g_param;
+  const double* g_at_psi;
+  const double* g_table;
+  double* ws;  // [ncol][rec_len]
+};
+
+struct SolveArgs {
+  int ncol, nb, nz, reclen;
+  long long col_stride;
+  const double* ws;  // K0 records
+  const double* I_dr0;
+  const double* I_df0;
+  const double* leaf_r;
+  const double* leaf_t;
+  const double* soil_r;
+  double* o[7];  // I_dr, I_df_d, I_df_u, F, x0, x1, x2
+  double mu_s;
+};
+
+// ------------------------------------------------------------------------------------------
+// G(psi) closed forms on device (crt1d/leaf_angle.py:118-202); `cs`, `sn` = cos/sin(psi).
+// Ellipsoidal forms use sqrt(x^2 cos^2 + sin^2)/p2 == sqrt(x^2 + tan^2)/p2 * cos, finite at pi/2.
+__device__ inline double ellipsoidal_p2(double x) {
+  if (x > 1.0) {
+    double e = sqrt(1.0 - 1.0 / (x * x));
+    return x + log((1.0 + e) / (1.0 - e)) / (2.0 * e * x);
+  }
+  double e = sqrt(1.0 - x * x);
+  return x + asin(e) / e;
+}
+
+__device__ inline double G_closed(int kind, double param, double cs, double sn) {
+  switch (kind) {
+    case CRT_G_HORIZONTAL: return cs;
+    case CRT_G_SPHERICAL: return 0.5;
+    case CRT_G_VERTICAL: return 0.63661977236758134308 * sn;  // 2/pi
+    case CRT_G_ELLIPSOIDAL: {
+      if (param == 1.0) return 0.5;
+      return sqrt(param * param * cs * cs + sn * sn) / ellipsoidal_p2(param);
+    }
+    case CRT_G_ELLIPSOIDAL_APPROX: {
+      double p2 = param + 1.774 * pow(param + 1.182, -0.733);
+      return sqrt(param * param * cs * cs + sn * sn) / p2;
+    }
+    case CRT_G_ELLIPSOIDAL_APPROX_BONAN: {
+      double chil = fmin(fmax(param, -0.4), 0.6);
+      double phi1 = 0.5 - 0.633 * chil - 0.330 * chil * chil;
+      double phi2 = 0.877 * (1.0 - 2.0 * phi1);
+      return phi1 + phi2 * cs;
+    }
+    default: return 0.0 / 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Work decomposition of every solve kernel: one lane owns VEC adjacent bands of one column and
+// sweeps the canopy levels; consecutive lanes own consecutive bands, so each per-level store of a
+// wave is one contiguous 512-B (VEC=1) or 1-KiB (VEC=2) segment of the band-contiguous output.
+// A block covers BLOCK consecutive (column, band-group) items, i.e. at most
+// (BLOCK-1)/nbv + 2 columns, whose K0 records are contiguous in the workspace and are staged
+// into LDS with one coalesced copy.
+struct Item {
+  int c;          // column
+  int b;          // first band
+  int c_first;    // first column of this block
+  bool active;
+};
+
+template <int BLOCK, int VEC>
+__device__ inline Item locate(int ncol, int nb) {
+  const int nbv = nb / VEC;
+  const long long first = (long long)blockIdx.x * BLOCK;
+  const long long item = first + threadIdx.x;
+  Item it;
+  it.c_first = (int)(first / nbv);
+  it.active = item < (long long)ncol * nbv;
+  const long long itc = it.active ? item : first;
+  it.c = (int)(itc / nbv);
+  it.b = (int)(itc - (long long)it.c * nbv) * VEC;
+  return it;
+}
+
+// copy the block's column records global -> LDS (USE_LDS) and return this lane's record base
+template <int BLOCK, int VEC, bool USE_LDS>
+__device__ inline const double* stage_records(const SolveArgs& a, const Item& it, double* lds) {
+  if constexpr (USE_LDS) {
+    const int nbv = a.nb / VEC;
+    const long long first = (long long)blockIdx.x * BLOCK;
+    long long last = first + BLOCK - 1;
+    const long long total = (long long)a.ncol * nbv;
+    if (last >= total) last = total - 1;
+    const int c_last = (int)(last / nbv);
+    const int n = (c_last - it.c_first + 1) * a.reclen;
+    const double* src = a.ws + (long long)it.c_first * a.reclen;
+    for (int i = threadIdx.x; i < n; i += BLOCK) lds[i] = src[i];
+    __syncthreads();
+    return lds + (it.c - it.c_first) * a.reclen;
+  } else {
+    return a.ws + (long long)it.c * a.reclen;
+  }
+}
+
+// streaming (write-once) stores: outputs are never re-read by the kernel
+template <int VEC>
+struct Pack;
+template <>
+struct Pack<1> {
+  typedef double type;
+};
+template <>
+struct Pack<2> {
+  typedef double type __attribute__((ext_vector_type(2)));
+};
+
+template <int VEC>
+__device__ inline void store_stream(double* p, const double (&v)[VEC]) {
+  if constexpr (VEC == 1) {
+    __builtin_nontemporal_store(v[0], p);
+  } else {
+    typename Pack<2>::type t;
+    t.x = v[0];
+    t.y = v[1];
+    __builtin_nontemporal_store(t, reinterpret_cast<typename Pack<2>::type*>(p));
+  }
+}
+
+// launchers implemented in the .hip files
+int launch_colpre(const ColArgs& a, hipStream_t s);
+int launch_closed(int scheme, const SolveArgs& a, hipStream_t s);
+int launch_tridiag(int scheme, const SolveArgs& a, hipStream_t s);
+int init_quadrature(hipStream_t s);
+void host_quad_nodes(double mu_s, double* psi_nodes);
+
+}  // namespace crt

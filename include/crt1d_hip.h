@@ -1,0 +1,163 @@
+/*
+ * crt1d_hip.h -- C ABI of the MI355X (gfx950) batched 1-D canopy radiative-transfer path.
+ *
+ * One call = one scheme over a batch of (column x band) solves.  The entry points replace,
+ * for the batched case, the reference's keyword-only plugin functions
+ *
+ *   solve_2s   crt1d/solvers/_solve_2s.py:11-163     ->  crt_hip_2s_f64
+ *   solve_4s   crt1d/solvers/_solve_4s.py:8-293      ->  crt_hip_4s_f64
+ *   solve_n79  crt1d/solvers/_solve_n79.py:11-164    ->  crt_hip_n79_f64
+ *   solve_zq   crt1d/solvers/_solve_zq.py:13-229     ->  crt_hip_zq_f64
+ *   solve_bl   crt1d/solvers/_solve_bl.py:9-93       ->  crt_hip_bl_f64
+ *   solve_g77  crt1d/solvers/_solve_g77.py:7-135     ->  crt_hip_g77_f64
+ *   solve_bf   crt1d/solvers/_solve_bf.py:7-154      ->  crt_hip_bf_f64
+ *
+ * which `Model.run` dispatches to at crt1d/model.py:305-310.  The reference has no FFI of
+ * its own (pure Python); INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers + sizes; all data pointers are DEVICE pointers (HBM), fp64, caller-owned.
+ *    Nothing is allocated or freed by the library; launches are asynchronous on `stream`.
+ *  - `lai` is cumulative leaf-area index from the canopy top: index 0 = ground (total LAI),
+ *    index nz-1 = canopy top (0), strictly as crt1d/variables.yml:73-86 / model.py:244-246.
+ *  - per-(column, band) inputs: element (c, b) at p[c * col_stride + b]; col_stride = 0
+ *    broadcasts one spectrum over all columns.
+ *  - outputs are [ncol][nz or nz-1][nb], bands contiguous (the reference's (nz, nb) C-order
+ *    arrays, stacked over columns).
+ *  - return value: 0 on success, negative crt_status otherwise (the Python wrapper maps these
+ *    to the reference's exception types: AssertionError / ValueError).
+ *  - thread-safety: re-entrant; concurrent calls must use distinct streams + workspaces.
+ */
+#ifndef CRT1D_HIP_H
+#define CRT1D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRT_ABI_VERSION 1
+
+/* leaf-angle G(psi) kinds: crt1d/leaf_angle.py:118-202 */
+enum crt_g_kind {
+  CRT_G_HORIZONTAL = 0,              /* cos(psi)                       :118-120 */
+  CRT_G_SPHERICAL = 1,               /* 0.5                            :123-125 */
+  CRT_G_VERTICAL = 2,                /* 2/pi sin(psi)                  :128-130 */
+  CRT_G_ELLIPSOIDAL = 3,             /* Campbell 1986, param = x       :133-165 */
+  CRT_G_ELLIPSOIDAL_APPROX = 4,      /* Campbell 1990, param = x       :168-180 */
+  CRT_G_ELLIPSOIDAL_APPROX_BONAN = 5,/* Ross-Goudriaan, param = chi_l  :183-202 */
+  CRT_G_TABLE = 6                    /* caller-sampled callable (K_b_fn / G_fn of the plugin API) */
+};
+
+/* fixed quadrature nodes at which a CRT_G_TABLE column supplies G(psi) */
+#define CRT_NQ_TAU 96  /* graded composite Gauss-Legendre on [0, pi/2]: tau_d (common.py:30-37), mu_bar (_solve_2s.py:32) */
+#define CRT_NQ_G4 32   /* 2 x 16 Gauss-Legendre in psi for G_int_1/2 (_solve_4s.py:148-149); depend on mu_s */
+#define CRT_NQ_9SKY 9  /* 5,15,...,85 deg (common.py:46) */
+#define CRT_NQ (CRT_NQ_TAU + CRT_NQ_G4 + CRT_NQ_9SKY)
+
+enum crt_scheme {
+  CRT_SCHEME_2S = 0, CRT_SCHEME_4S = 1, CRT_SCHEME_N79 = 2, CRT_SCHEME_ZQ = 3,
+  CRT_SCHEME_BL = 4, CRT_SCHEME_G77 = 5, CRT_SCHEME_BF = 6, CRT_NUM_SCHEMES = 7
+};
+
+enum crt_tau_d_method { CRT_TAU_D_QUAD = 0, CRT_TAU_D_9SKY = 1 }; /* _solve_n79.py:19, common.py:72-78 */
+
+enum crt_status {
+  CRT_OK = 0,
+  CRT_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, bad enum  -> ValueError      */
+  CRT_ERR_WORKSPACE = -2,    /* workspace smaller than crt_hip_workspace_bytes()              */
+  CRT_ERR_UNSUPPORTED = -3,  /* shape outside what the kernels handle (e.g. nz too large for LDS) */
+  CRT_ERR_LAUNCH = -4,       /* HIP launch / runtime error                                    */
+  CRT_ERR_SHAPE = -5         /* shape violates a reference assertion (e.g. nz < 3 for n79) -> AssertionError */
+};
+
+typedef void* crt_stream_t; /* hipStream_t */
+
+/* per-column canopy geometry (what one reference `Model` instance holds; model.py:68-116) */
+typedef struct crt_columns {
+  int32_t ncol;
+  int32_t nz;             /* interface levels ("nlayers" of the reference) */
+  const double* psi;      /* [ncol] solar zenith angle, radians */
+  const double* lai;      /* [ncol][nz] cumulative LAI, index 0 = ground */
+  const double* mla;      /* [ncol] mean leaf angle, degrees; 2s only (may be NULL otherwise) */
+  const int32_t* g_kind;  /* [ncol] crt_g_kind */
+  const double* g_param;  /* [ncol] x or chi_l (ignored for parameter-free kinds) */
+  const double* g_at_psi; /* [ncol] G(psi[c]); read only for CRT_G_TABLE columns (may be NULL otherwise) */
+  const double* g_table;  /* [ncol][CRT_NQ] G at crt_hip_quad_nodes(); CRT_G_TABLE columns only (may be NULL) */
+} crt_columns;
+
+/* per-(column, band) spectra: the (n_wl,) plugin inputs I_dr0_all, I_df0_all, leaf_r, leaf_t, soil_r */
+typedef struct crt_bands {
+  int32_t nb;
+  int64_t col_stride;     /* nb (or larger) for per-column spectra, 0 = same spectrum for every column */
+  const double* I_dr0;
+  const double* I_df0;
+  const double* leaf_r;
+  const double* leaf_t;
+  const double* soil_r;   /* not read by bl */
+} crt_bands;
+
+/* crt_options.flags */
+#define CRT_FLAG_SKIP_PRECOMPUTE 1 /* workspace already holds the column records of an earlier call with the
+                                      same scheme/columns/options (only the spectra changed): skip kernel K0 */
+#define CRT_FLAG_PRECOMPUTE_ONLY 2 /* run K0 only (fills the workspace), no solve kernel */
+
+typedef struct crt_options {
+  double mu_s;            /* 4s: cosine of the dividing angle, default 0.501 (_solve_4s.py:9) */
+  int32_t tau_d_method;   /* n79: crt_tau_d_method, default CRT_TAU_D_QUAD (_solve_n79.py:19) */
+  int32_t flags;          /* CRT_FLAG_* */
+} crt_options;
+
+/* outputs; each [ncol][nz][nb] unless noted.  Unused slots may be NULL. */
+typedef struct crt_outputs {
+  double* I_dr;
+  double* I_df_d;
+  double* I_df_u;
+  double* F;
+  double* x0; /* n79: aI_lsl [ncol][nz-1][nb] | zq: I_df_d_ss | g77, bf: aI_lsl */
+  double* x1; /* n79: aI_lsh [ncol][nz-1][nb] | zq: I_df_u_ss | g77, bf: aI_lsh */
+  double* x2; /*                                zq: F_ss      | g77, bf: aI_l   */
+} crt_outputs;
+
+int crt_hip_abi_version(void);
+const char* crt_hip_strerror(int status);
+
+/* bytes of device workspace a solve of `scheme` needs for (ncol, nz) */
+size_t crt_hip_workspace_bytes(int scheme, int32_t ncol, int32_t nz);
+
+/* host: fill psi_nodes[CRT_NQ] with the zenith angles (radians) at which g_table is sampled */
+int crt_hip_quad_nodes(double mu_s, double* psi_nodes);
+
+/* generic entry (scheme = crt_scheme) and the per-scheme entry points */
+int crt_hip_solve_f64(int scheme, const crt_columns* cols, const crt_bands* bands, const crt_options* opts,
+                      const crt_outputs* out, void* workspace, size_t workspace_bytes, crt_stream_t stream);
+int crt_hip_2s_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
+int crt_hip_4s_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
+int crt_hip_n79_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
+int crt_hip_zq_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
+int crt_hip_bl_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
+int crt_hip_g77_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
+int crt_hip_bf_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
+
+/*
+ * Epilogue (model.py:573-647 `_calc_absorption` + diagnostics.py:39-108 `band`): layer absorption
+ * from the three irradiance profiles, reduced over bands with `ngroup` weight vectors
+ * (spectra.py:71-126 `_x_frac_in_bounds`).  Outputs, each [ncol][nz-1][ngroup]:
+ *   aI (total), aI_sl (sunlit), aI_sh (shaded); and totals [ncol][ngroup][4]:
+ *   incoming I_d[top], reflected I_df_u[top], transmitted I_d[ground], soil-reflected I_df_u[ground]
+ *   (the terms of diagnostics.py:476-530 `compare_ebal`).  band_w is [ngroup][nb].
+ */
+int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, const double* I_dr, const double* I_df_d,
+                               const double* I_df_u, const double* band_w, int32_t ngroup, double* aI, double* aI_sl,
+                               double* aI_sh, double* totals, crt_stream_t stream);
+
+/* bandwidth probes used by bench.py to report a measured HBM ceiling next to the 8 TB/s spec */
+int crt_hip_probe_fill_f64(double* dst, size_t n, double value, crt_stream_t stream);
+int crt_hip_probe_copy_f64(double* dst, const double* src, size_t n, crt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRT1D_HIP_H */

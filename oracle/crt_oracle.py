@@ -562,11 +562,13 @@ def solve_4s(cols, *, I_dr0, I_df0, leaf_r, leaf_t, soil_r, mu_s=0.501, method="
             g = Gp[c] * np.array([e2 / mu_2, e1 / mu_1, -e1 / mu_1, -e2 / mu_2])
             x = lai[c]
             if method == "eig":
+                # eigenvalues come in +-lambda pairs; for strongly scattering leaves one pair can be
+                # purely imaginary (oscillatory modes) -- the reference's BVP solver integrates those
+                # just the same, so keep complex arithmetic and take the real part at the end
                 lam, V = np.linalg.eig(A)
-                lam, V = lam.real, V.real
                 p = np.linalg.solve(A + kap * np.eye(4), -g)
                 # scaled modes: growing ones anchored at x = LAI
-                x0 = np.where(lam > 0, LAI[c], 0.0)
+                x0 = np.where(lam.real > 0, LAI[c], 0.0)
                 mode = lambda xx: V * np.exp(lam * (xx - x0))[None, :]  # noqa: E731  (4, 4): column k = mode k
                 M0, ML = mode(0.0), mode(LAI[c])
                 eL = math.exp(-kap * LAI[c])
@@ -579,7 +581,7 @@ def solve_4s(cols, *, I_dr0, I_df0, leaf_r, leaf_t, soil_r, mu_s=0.501, method="
                 ])
                 cf = np.linalg.solve(Mat, rhs)
                 E = np.exp(lam[None, :] * (x[:, None] - x0[None, :]))  # (nz, 4)
-                Y = (E * cf[None, :]) @ V.T + np.exp(-kap * x)[:, None] * p[None, :]  # (nz, 4)
+                Y = ((E * cf[None, :]) @ V.T).real + np.exp(-kap * x)[:, None] * p[None, :]  # (nz, 4)
             elif method == "bvp":
                 from scipy import integrate
 

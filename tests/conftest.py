@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, f"{name}.npz"))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import crt_oracle
+
+    return crt_oracle
+
+
+def rel_profile_err(got, ref):
+    """max over everything of |got - ref| / (max |ref| over the level axis of that (column, band))."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    ax = got.ndim - 2  # level axis of (..., nz, nb)
+    scale = np.abs(ref).max(axis=ax, keepdims=True)
+    scale = np.where(scale == 0, 1.0, scale)
+    return float(np.max(np.abs(got - ref) / scale))
+
+
+def rel_elem_err(got, ref, floor=0.0):
+    got, ref = np.asarray(got), np.asarray(ref)
+    den = np.maximum(np.abs(ref), floor)
+    m = den > 0
+    return float(np.max(np.abs(got - ref)[m] / den[m])) if m.any() else 0.0
