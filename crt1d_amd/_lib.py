@@ -18,6 +18,7 @@ NQ = NQ_TAU + NQ_G4 + NQ_9SKY
 
 FLAG_SKIP_PRECOMPUTE = 1
 FLAG_PRECOMPUTE_ONLY = 2
+FLAG_DIRECT_STORES = 4
 
 CRT_OK = 0
 CRT_ERR_BAD_ARG = -1
@@ -77,6 +78,7 @@ EXPORTS = [
     "crt_hip_g77_f64",
     "crt_hip_bf_f64",
     "crt_hip_absorb_bandsum_f64",
+    "crt_hip_tune",
     "crt_hip_probe_fill_f64",
     "crt_hip_probe_copy_f64",
 ]
@@ -129,6 +131,8 @@ def load():
     lib.crt_hip_absorb_bandsum_f64.argtypes = [
         ctypes.POINTER(CrtColumns), ctypes.POINTER(CrtBands), _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp,
     ]
+    lib.crt_hip_tune.restype = None
+    lib.crt_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.crt_hip_probe_fill_f64.restype = ctypes.c_int
     lib.crt_hip_probe_fill_f64.argtypes = [_vp, ctypes.c_size_t, ctypes.c_double, _vp]
     lib.crt_hip_probe_copy_f64.restype = ctypes.c_int

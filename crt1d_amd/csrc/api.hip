@@ -238,7 +238,8 @@ int crt_hip_solve_f64(int scheme, const crt_columns* cols, const crt_bands* band
   sa.o[5] = out->x1;
   sa.o[6] = out->x2;
   sa.mu_s = mu_s;
-  return tri ? launch_tridiag(scheme, sa, s) : launch_closed(scheme, sa, s);
+  const int force = (flags & CRT_FLAG_DIRECT_STORES) ? 1 : 0;
+  return tri ? launch_tridiag(scheme, sa, s, force) : launch_closed(scheme, sa, s, force);
 }
 
 #define CRT_ENTRY(name, id)                                                                                        \
@@ -286,16 +287,18 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 
+void crt_hip_tune(int key, int value) { tune_closed(key, value); }
+
 int crt_hip_probe_fill_f64(double* dst, size_t n, double value, crt_stream_t stream) {
   if (!dst || n == 0 || (n & 1) || (reinterpret_cast<uintptr_t>(dst) & 15)) return CRT_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_fill, dim3(256 * 8), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<d2*>(dst), n / 2, value);
+  hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<d2*>(dst), n / 2, value);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 
 int crt_hip_probe_copy_f64(double* dst, const double* src, size_t n, crt_stream_t stream) {
   if (!dst || !src || n == 0 || (n & 1) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15))
     return CRT_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_copy, dim3(256 * 8), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<d2*>(dst),
+  hipLaunchKernelGGL(k_copy, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<d2*>(dst),
                      reinterpret_cast<const d2*>(src), n / 2);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }

@@ -181,9 +181,10 @@ __device__ inline void store_stream(double* p, const double (&v)[VEC]) {
 
 // launchers implemented in the .hip files
 int launch_colpre(const ColArgs& a, hipStream_t s);
-int launch_closed(int scheme, const SolveArgs& a, hipStream_t s);
-int launch_tridiag(int scheme, const SolveArgs& a, hipStream_t s);
+int launch_closed(int scheme, const SolveArgs& a, hipStream_t s, int force);
+int launch_tridiag(int scheme, const SolveArgs& a, hipStream_t s, int force);
 int init_quadrature(hipStream_t s);
+void tune_closed(int key, int value);
 void host_quad_nodes(double mu_s, double* psi_nodes);
 
 }  // namespace crt

@@ -1,243 +1,212 @@
 // Closed-form schemes: 2s, 4s, bl, g77, bf (gfx950).
 //
-// Mapping (all kernels): one lane owns VEC adjacent bands of one column, computes the per-band
-// coefficients once in registers, then sweeps the nz canopy levels.  Per level it reads the
-// band-independent column vectors (lai_j, exp(-K_b lai_j), ...) from the K0 record staged in LDS
-// (same address for the whole wave -> LDS broadcast, no vmem traffic in the loop besides stores)
-// and issues one streaming store per output array; a wave's store is one contiguous 512-B
-// (VEC=1) / 1-KiB (VEC=2) run of the band-contiguous [ncol][nz][nb] output.
-// The kernels are HBM-write-bound: 4-7 fp64 profiles out per 5 fp64 scalars in.
+// Every scheme is a small per-lane state object: init() turns one band's optical properties plus the
+// column's K0 record into a handful of register-resident coefficients, level(j) evaluates the
+// NARR output profiles at canopy level j from the band-independent column vectors (lai_j,
+// exp(-K_b lai_j), ...) that sit in LDS (same address for the whole wave -> LDS broadcast).
+// One lane owns one (column, band) and sweeps the levels.
+//
+// The kernels are HBM-WRITE-bound (4-7 fp64 profiles out per 5 fp64 scalars in), so the store
+// pattern decides the speed.  Measured on MI355X (tools/store_bw*.hip, profiles/r01_store_patterns.md):
+// lanes storing their own band directly write, per level, a 512-B/1-KiB run whose start is only
+// 8-B aligned whenever a row of nb doubles is not a multiple of 128 B (nb = 300: 2400 B) --
+// 3.0-3.9 TB/s; the same bytes written as 128-B-aligned contiguous chunks reach 5.5 TB/s
+// (the L2 does not merge partial lines, not even between waves of one CU).  Hence two kernels:
+//
+//  k_tile   (default, nb >= 64): a workgroup owns CB whole columns.  Because the output is
+//           [ncol][nz][nb] with bands contiguous, T consecutive levels of one column form ONE
+//           contiguous run of T*nb doubles.  The lanes write their values into an LDS tile laid out
+//           exactly like that run; after T levels the workgroup flushes the run with 16-B-per-lane
+//           stores at consecutive addresses, so every wave store covers 8 whole 128-B lines.
+//           T = 16/gcd(nb,16) (times a small factor) makes every run start on a line boundary.
+//  k_direct (small nb, or tile does not fit in LDS): the original lane-stores-its-band kernel.
 #include "crt_internal.hpp"
 
 namespace crt {
 namespace {
 
-constexpr int BLOCK = 256;
 constexpr double PI = 3.14159265358979323846;
 
 struct BandIn {
   double I_dr0, I_df0, r, t, s;
 };
 
-template <int VEC>
-__device__ inline void load_bands(const SolveArgs& a, const Item& it, bool need_soil, BandIn (&in)[VEC]) {
-  const long long base = (long long)it.c * a.col_stride + it.b;
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    in[v].I_dr0 = a.I_dr0[base + v];
-    in[v].I_df0 = a.I_df0[base + v];
-    in[v].r = a.leaf_r[base + v];
-    in[v].t = a.leaf_t[base + v];
-    in[v].s = need_soil ? a.soil_r[base + v] : 0.0;
-  }
+__device__ inline BandIn load_band(const SolveArgs& a, int c, int b, bool need_soil) {
+  const long long i = (long long)c * a.col_stride + b;
+  BandIn in;
+  in.I_dr0 = a.I_dr0[i];
+  in.I_df0 = a.I_df0[i];
+  in.r = a.leaf_r[i];
+  in.t = a.leaf_t[i];
+  in.s = need_soil ? a.soil_r[i] : 0.0;
+  return in;
 }
 
 // ------------------------------------------------------------------------------------------
 // 2s  Dickinson-Sellers two-stream (crt1d/solvers/_solve_2s.py:54-156)
-struct Coef2s {
+struct Sch2s {
+  static constexpr int NARR = 4;
+  static constexpr bool SOIL = true;
   double h;                       // diffuse extinction              :84
   double Au, Bu, Cu, Ad, Bd, Cd;  // up/dn = A e^{-KL} + B e^{-hL} + C e^{+hL}   :125-135
-  double I0;
-};
+  double I0, invmu;
 
-__device__ inline Coef2s coef_2s(const double* rec, const BandIn& in) {
-  const double K = rec[S_KB], mu = rec[S_MU], mb = rec[S_MUBAR], cos2 = rec[S_COS2], LT = rec[S_LT];
-  const double al = in.r, ta = in.t, rs = in.s;
-  const double om = al + ta;                                         // :65
-  const double beta = 0.5 * (al + ta + (al - ta) * cos2) / om;       // :68
-  const double a_s = om / 2 * (1 - mu * log((mu + 1) / mu));         // :73
-  const double mbK = mb * K;
-  const double beta0 = (1 + mbK) / (om * mbK) * a_s;                 // :76
-  const double b = 1 - (1 - beta) * om;                              // :80
-  const double c = om * beta;
-  const double d = om * mbK * beta0;
-  const double f = om * mbK * (1 - beta0);
-  const double h = sqrt(b * b - c * c) / mb;
-  const double sig = mbK * mbK + c * c - b * b;                      // :85
-  const double u1 = b - c / rs;                                      // :87
-  const double u2 = b - c * rs;
-  const double u3 = f + c * rs;
-  const double S1 = exp(-h * LT);
-  const double S2 = exp(-K * LT);
-  const double mh = mb * h;
-  const double p1 = b + mh, p2 = b - mh, p3 = b + mbK, p4 = b - mbK;
-  const double iS1 = 1.0 / S1;
-  const double D1 = p1 * (u1 - mh) * iS1 - p2 * (u1 + mh) * S1;      // :96
-  const double D2 = (u2 + mh) * iS1 - (u2 - mh) * S1;
-  const double iD1 = 1.0 / D1, iD2 = 1.0 / D2, isig = 1.0 / sig;
-  const double h1 = -d * p4 - c * f;                                 // :99
-  const double h1s = h1 * isig;
-  const double t1 = d - h1s * p3;
-  const double t2 = d - c - h1s * (u1 + mbK);
-  const double h2 = iD1 * (t1 * (u1 - mh) * iS1 - p2 * t2 * S2);
-  const double h3 = -iD1 * (t1 * (u1 + mh) * S1 - p1 * t2 * S2);
-  const double h4 = -f * p3 - c * d;                                 // :108 (Sellers 1996)
-  const double h4s = h4 * isig;
-  const double t3 = u3 - h4s * (u2 - mbK);
-  const double h5 = -iD2 * (h4s * (u2 + mh) * iS1 + t3 * S2);
-  const double h6 = iD2 * (h4s * (u2 - mh) * S1 + t3 * S2);
-  const double h7 = c * iD1 * (u1 - mh) * iS1;
-  const double h8 = -c * iD1 * (u1 + mh) * S1;
-  const double h9 = iD2 * (u2 + mh) * iS1;
-  const double h10 = -iD2 * (u2 - mh) * S1;                          // :120
-  Coef2s k;
-  k.h = h;
-  k.I0 = in.I_dr0;
-  k.Au = in.I_dr0 * h1s;
-  k.Bu = in.I_dr0 * h2 + in.I_df0 * h7;
-  k.Cu = in.I_dr0 * h3 + in.I_df0 * h8;
-  k.Ad = in.I_dr0 * h4s;
-  k.Bd = in.I_dr0 * h5 + in.I_df0 * h9;
-  k.Cd = in.I_dr0 * h6 + in.I_df0 * h10;
-  return k;
-}
-
-template <int VEC, bool USE_LDS>
-__global__ __launch_bounds__(BLOCK) void k_2s(SolveArgs a) {
-  extern __shared__ double lds[];
-  const Item it = locate<BLOCK, VEC>(a.ncol, a.nb);
-  const double* rec = stage_records<BLOCK, VEC, USE_LDS>(a, it, lds);
-  if (!it.active) return;
-  BandIn in[VEC];
-  load_bands<VEC>(a, it, true, in);
-  Coef2s k[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) k[v] = coef_2s(rec, in[v]);
-  const double invmu = rec[S_INVMU];
-  const int nz = a.nz;
-  const double* lai = rec + REC_HDR;
-  const double* ekl = lai + nz;
-  long long o = ((long long)it.c * nz) * a.nb + it.b;
-  for (int j = 0; j < nz; ++j, o += a.nb) {
-    const double L = lai[j], eK = ekl[j];
-    double idr[VEC], dn[VEC], up[VEC], F[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const double em = exp(-k[v].h * L);
-      const double ep = 1.0 / em;
-      up[v] = k[v].Au * eK + k[v].Bu * em + k[v].Cu * ep;
-      dn[v] = k[v].Ad * eK + k[v].Bd * em + k[v].Cd * ep;
-      idr[v] = k[v].I0 * eK;                              // :150
-      F[v] = idr[v] * invmu + 2 * up[v] + 2 * dn[v];      // :156
-    }
-    store_stream<VEC>(a.o[0] + o, idr);
-    store_stream<VEC>(a.o[1] + o, dn);
-    store_stream<VEC>(a.o[2] + o, up);
-    store_stream<VEC>(a.o[3] + o, F);
+  __device__ inline void init(const double* rec, const BandIn& in, const SolveArgs&) {
+    const double K = rec[S_KB], mu = rec[S_MU], mb = rec[S_MUBAR], cos2 = rec[S_COS2], LT = rec[S_LT];
+    const double al = in.r, ta = in.t, rs = in.s;
+    const double om = al + ta;                                         // :65
+    const double beta = 0.5 * (al + ta + (al - ta) * cos2) / om;       // :68
+    const double a_s = om / 2 * (1 - mu * log((mu + 1) / mu));         // :73
+    const double mbK = mb * K;
+    const double beta0 = (1 + mbK) / (om * mbK) * a_s;                 // :76
+    const double b = 1 - (1 - beta) * om;                              // :80
+    const double c = om * beta;
+    const double d = om * mbK * beta0;
+    const double f = om * mbK * (1 - beta0);
+    h = sqrt(b * b - c * c) / mb;
+    const double sig = mbK * mbK + c * c - b * b;                      // :85
+    const double u1 = b - c / rs;                                      // :87
+    const double u2 = b - c * rs;
+    const double u3 = f + c * rs;
+    const double S1 = exp(-h * LT);
+    const double S2 = exp(-K * LT);
+    const double mh = mb * h;
+    const double p1 = b + mh, p2 = b - mh, p3 = b + mbK, p4 = b - mbK;
+    const double iS1 = 1.0 / S1;
+    const double D1 = p1 * (u1 - mh) * iS1 - p2 * (u1 + mh) * S1;      // :96
+    const double D2 = (u2 + mh) * iS1 - (u2 - mh) * S1;
+    const double iD1 = 1.0 / D1, iD2 = 1.0 / D2, isig = 1.0 / sig;
+    const double h1 = -d * p4 - c * f;                                 // :99
+    const double h1s = h1 * isig;
+    const double t1 = d - h1s * p3;
+    const double t2 = d - c - h1s * (u1 + mbK);
+    const double h2 = iD1 * (t1 * (u1 - mh) * iS1 - p2 * t2 * S2);
+    const double h3 = -iD1 * (t1 * (u1 + mh) * S1 - p1 * t2 * S2);
+    const double h4 = -f * p3 - c * d;                                 // :108 (Sellers 1996)
+    const double h4s = h4 * isig;
+    const double t3 = u3 - h4s * (u2 - mbK);
+    const double h5 = -iD2 * (h4s * (u2 + mh) * iS1 + t3 * S2);
+    const double h6 = iD2 * (h4s * (u2 - mh) * S1 + t3 * S2);
+    const double h7 = c * iD1 * (u1 - mh) * iS1;
+    const double h8 = -c * iD1 * (u1 + mh) * S1;
+    const double h9 = iD2 * (u2 + mh) * iS1;
+    const double h10 = -iD2 * (u2 - mh) * S1;                          // :120
+    I0 = in.I_dr0;
+    invmu = rec[S_INVMU];
+    Au = in.I_dr0 * h1s;
+    Bu = in.I_dr0 * h2 + in.I_df0 * h7;
+    Cu = in.I_dr0 * h3 + in.I_df0 * h8;
+    Ad = in.I_dr0 * h4s;
+    Bd = in.I_dr0 * h5 + in.I_df0 * h9;
+    Cd = in.I_dr0 * h6 + in.I_df0 * h10;
   }
-}
+
+  __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) const {
+    const double L = rec[REC_HDR + j], eK = rec[REC_HDR + nz + j];
+    const double em = exp(-h * L);
+    const double ep = 1.0 / em;
+    const double up = Au * eK + Bu * em + Cu * ep;
+    const double dn = Ad * eK + Bd * em + Cd * ep;
+    const double idr = I0 * eK;                    // :150
+    o[0] = idr;
+    o[1] = dn;
+    o[2] = up;
+    o[3] = idr * invmu + 2 * up + 2 * dn;          // :156
+  }
+};
 
 // ------------------------------------------------------------------------------------------
 // bl  Beer-Lambert (crt1d/solvers/_solve_bl.py:51-90)
-template <int VEC, bool USE_LDS>
-__global__ __launch_bounds__(BLOCK) void k_bl(SolveArgs a) {
-  extern __shared__ double lds[];
-  const Item it = locate<BLOCK, VEC>(a.ncol, a.nb);
-  const double* rec = stage_records<BLOCK, VEC, USE_LDS>(a, it, lds);
-  if (!it.active) return;
-  BandIn in[VEC];
-  load_bands<VEC>(a, it, false, in);
-  const double Kb = rec[S_KB], invmu = rec[S_INVMU];
-  double Kg[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) Kg[v] = Kb * sqrt(1 - (in[v].t + in[v].r));  // :58-62
-  const int nz = a.nz;
-  const double* lai = rec + REC_HDR;
-  const double* ekl = lai + nz;
-  const double* tdf = ekl + nz;
-  long long o = ((long long)it.c * nz) * a.nb + it.b;
-  for (int j = 0; j < nz; ++j, o += a.nb) {
-    const double L = lai[j], tb = ekl[j], td = tdf[j];
-    double idr[VEC], dn[VEC], up[VEC], F[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const double tg = exp(-Kg[v] * L);                                   // :65
-      idr[v] = in[v].I_dr0 * tb;                                           // :69
-      dn[v] = in[v].I_df0 * td + 0.5 * (in[v].I_dr0 * (tg - tb));          // :70,74,79
-      up[v] = 0.0;                                                         // :87
-      F[v] = idr[v] * invmu + 2 * dn[v];                                   // :90
-    }
-    store_stream<VEC>(a.o[0] + o, idr);
-    store_stream<VEC>(a.o[1] + o, dn);
-    store_stream<VEC>(a.o[2] + o, up);
-    store_stream<VEC>(a.o[3] + o, F);
+struct SchBl {
+  static constexpr int NARR = 4;
+  static constexpr bool SOIL = false;
+  double Kg, I_dr0, I_df0, invmu;
+
+  __device__ inline void init(const double* rec, const BandIn& in, const SolveArgs&) {
+    Kg = rec[S_KB] * sqrt(1 - (in.t + in.r));  // :58-62
+    I_dr0 = in.I_dr0;
+    I_df0 = in.I_df0;
+    invmu = rec[S_INVMU];
   }
-}
+  __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) const {
+    const double L = rec[REC_HDR + j], tb = rec[REC_HDR + nz + j], td = rec[REC_HDR + 2 * nz + j];
+    const double tg = exp(-Kg * L);                               // :65
+    const double idr = I_dr0 * tb;                                // :69
+    const double dn = I_df0 * td + 0.5 * (I_dr0 * (tg - tb));     // :70,74,79
+    o[0] = idr;
+    o[1] = dn;
+    o[2] = 0.0;                                                   // :87
+    o[3] = idr * invmu + 2 * dn;                                  // :90
+  }
+};
 
 // ------------------------------------------------------------------------------------------
 // g77 Goudriaan 1977 (crt1d/solvers/_solve_g77.py:48-124) and bf Bodin & Franklin
 // (crt1d/solvers/_solve_bf.py:60-140): same inputs/outputs, different scattered-light terms.
-template <int VEC, bool USE_LDS, bool BF>
-__global__ __launch_bounds__(BLOCK) void k_g77(SolveArgs a) {
-  extern __shared__ double lds[];
-  const Item it = locate<BLOCK, VEC>(a.ncol, a.nb);
-  const double* rec = stage_records<BLOCK, VEC, USE_LDS>(a, it, lds);
-  if (!it.active) return;
-  BandIn in[VEC];
-  load_bands<VEC>(a, it, true, in);
-  const double kb = rec[S_KB], mu = rec[S_MU], invmu = rec[S_INVMU], LT = rec[S_LT];
-  const int nz = a.nz;
-  const double* lai = rec + REC_HDR;
-  const double* ekl = lai + nz;
-  const double A0 = ekl[0];  // A_sl at the ground level
-  double kp[VEC], kd[VEC], omr[VEC], cdf[VEC], csr[VEC], ct[VEC], gnd[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    const double sigma = in[v].r + in[v].t;                                       // g77:57
-    kp[v] = sqrt(1 - sigma);                                                      // :59
-    const double rho_c = ((1 - kp[v]) / (1 + kp[v])) * (2 / (1 + 1.6 * mu));      // :66
-    omr[v] = BF ? 1.0 : (1 - rho_c);                                              // bf:84 drops (1 - rho_c)
-    kd[v] = 0.8 * sqrt(1 - sigma);                                                // :69
-    cdf[v] = kd[v] / kp[v];
-    csr[v] = kd[v] / sqrt(1 - in[v].r);
-    ct[v] = kd[v] / sqrt(1 - in[v].t);
+template <bool BF>
+struct SchG77 {
+  static constexpr int NARR = 7;
+  static constexpr bool SOIL = true;
+  double kb, invmu, LT, kp, kd, omr, cdf, csr, ct, gnd, I_dr0, I_df0, r, t;
+
+  __device__ inline void init(const double* rec, const BandIn& in, const SolveArgs& a) {
+    kb = rec[S_KB];
+    invmu = rec[S_INVMU];
+    LT = rec[S_LT];
+    const double mu = rec[S_MU];
+    const double A0 = rec[REC_HDR + a.nz];  // A_sl at the ground level (ekl[0])
+    I_dr0 = in.I_dr0;
+    I_df0 = in.I_df0;
+    r = in.r;
+    t = in.t;
+    const double sigma = in.r + in.t;                                        // g77:57
+    kp = sqrt(1 - sigma);                                                    // :59
+    const double rho_c = ((1 - kp) / (1 + kp)) * (2 / (1 + 1.6 * mu));       // :66
+    omr = BF ? 1.0 : (1 - rho_c);                                            // bf:84 drops (1 - rho_c)
+    kd = 0.8 * sqrt(1 - sigma);                                              // :69
+    cdf = kd / kp;
+    csr = kd / sqrt(1 - in.r);
+    ct = kd / sqrt(1 - in.t);
     // ground-level terms for the soil-reflected stream (g77:95, bf:112)
-    const double ed0 = exp(-kd[v] * LT);
-    const double Idf0 = in[v].I_df0 * omr[v] * ed0;
+    const double ed0 = exp(-kd * LT);
+    const double Idf0 = in.I_df0 * omr * ed0;
     double Iscd0;
     if (BF)
-      Iscd0 = in[v].I_dr0 * in[v].t * ((A0 - ed0) / (kd[v] - kb));                // bf:95
+      Iscd0 = in.I_dr0 * in.t * ((A0 - ed0) / (kd - kb));                    // bf:95
     else
-      Iscd0 = 0.5 * (in[v].I_dr0 * (1 - rho_c) * exp(-kp[v] * kb * LT) - in[v].I_dr0 * (1 - sigma) * A0);
-    gnd[v] = in[v].s * (in[v].I_dr0 * A0 + Idf0 + Iscd0);
+      Iscd0 = 0.5 * (in.I_dr0 * (1 - rho_c) * exp(-kp * kb * LT) - in.I_dr0 * (1 - sigma) * A0);
+    gnd = in.s * (in.I_dr0 * A0 + Idf0 + Iscd0);
   }
-  long long o = ((long long)it.c * nz) * a.nb + it.b;
-  for (int j = 0; j < nz; ++j, o += a.nb) {
-    const double L = lai[j], Asl = ekl[j];
-    double idr[VEC], dn[VEC], up[VEC], F[VEC], asl[VEC], ash[VEC], al[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const double ed = exp(-kd[v] * L);
-      const double Idf = in[v].I_df0 * omr[v] * ed;                               // g77:73 / bf:84
-      double Iscd, Iscu;
-      if (BF) {
-        Iscd = in[v].I_dr0 * in[v].t * ((Asl - ed) / (kd[v] - kb));               // bf:95
-        Iscu = in[v].I_dr0 * in[v].r * ((Asl - exp(kd[v] * L - (kb + kd[v]) * LT)) / (kd[v] + kb));  // bf:99-103
-      } else {
-        const double sigma = in[v].r + in[v].t;
-        const double Isc = in[v].I_dr0 * omr[v] * exp(-kp[v] * kb * L) - in[v].I_dr0 * (1 - sigma) * Asl;  // g77:84-86
-        Iscd = 0.5 * Isc;
-        Iscu = 0.5 * Isc;
-      }
-      const double Isr = gnd[v] * exp(-kd[v] * (LT - L));                         // g77:95
-      const double common = cdf[v] * Idf + csr[v] * Iscu + ct[v] * Iscd;
-      ash[v] = (1 - Asl) * common;                                                // :99-101
-      asl[v] = Asl * (common + kb * in[v].I_dr0);                                 // :106-111
-      al[v] = asl[v] + ash[v];
-      idr[v] = in[v].I_dr0 * Asl;                                                 // :77
-      dn[v] = Iscd + Idf;                                                         // :115
-      up[v] = Iscu + Isr;                                                         // :116
-      F[v] = idr[v] * invmu + 2 * up[v] + 2 * dn[v];                              // :122
+  __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) const {
+    const double L = rec[REC_HDR + j], Asl = rec[REC_HDR + nz + j];
+    const double ed = exp(-kd * L);
+    const double Idf = I_df0 * omr * ed;                                     // g77:73 / bf:84
+    double Iscd, Iscu;
+    if (BF) {
+      Iscd = I_dr0 * t * ((Asl - ed) / (kd - kb));                           // bf:95
+      Iscu = I_dr0 * r * ((Asl - exp(kd * L - (kb + kd) * LT)) / (kd + kb)); // bf:99-103
+    } else {
+      const double sigma = r + t;
+      const double Isc = I_dr0 * omr * exp(-kp * kb * L) - I_dr0 * (1 - sigma) * Asl;  // g77:84-86
+      Iscd = 0.5 * Isc;
+      Iscu = 0.5 * Isc;
     }
-    store_stream<VEC>(a.o[0] + o, idr);
-    store_stream<VEC>(a.o[1] + o, dn);
-    store_stream<VEC>(a.o[2] + o, up);
-    store_stream<VEC>(a.o[3] + o, F);
-    store_stream<VEC>(a.o[4] + o, asl);
-    store_stream<VEC>(a.o[5] + o, ash);
-    store_stream<VEC>(a.o[6] + o, al);
+    const double Isr = gnd * exp(-kd * (LT - L));                            // g77:95
+    const double common = cdf * Idf + csr * Iscu + ct * Iscd;
+    const double ash = (1 - Asl) * common;                                   // :99-101
+    const double asl = Asl * (common + kb * I_dr0);                          // :106-111
+    const double idr = I_dr0 * Asl;                                          // :77
+    const double dn = Iscd + Idf;                                            // :115
+    const double up = Iscu + Isr;                                            // :116
+    o[0] = idr;
+    o[1] = dn;
+    o[2] = up;
+    o[3] = idr * invmu + 2 * up + 2 * dn;                                    // :122
+    o[4] = asl;
+    o[5] = ash;
+    o[6] = asl + ash;
   }
-}
+};
 
 // ------------------------------------------------------------------------------------------
 // 4s  Tian et al. (2007) four-stream (crt1d/solvers/_solve_4s.py:161-290).
@@ -253,15 +222,8 @@ __global__ __launch_bounds__(BLOCK) void k_g77(SolveArgs a) {
 // problems are linear in their data, so they are solved once, summed.  The four boundary
 // conditions (:110-116, :128-138) give a 4x4 linear system solved in registers by Gaussian
 // elimination with branch-free partial pivoting.
-struct Coef4s {
-  double lam1, lam2;  // sqrt(|l1|), sqrt(|l2|)
-  bool osc;           // l2 < 0
-  double d[5], u[5];  // I_df_d / I_df_u = sum_k coef[k] * phi_k(x), phi = {E1, F1, phi3, phi4, e^{-kappa x}}
-  double I0;
-};
-
 __device__ inline void solve4(double (&A)[4][5]) {
-  // Gaussian elimination, partial pivoting by conditional row swaps (no dynamic register indexing)
+  // partial pivoting by conditional row swaps (no dynamic register indexing)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -291,209 +253,363 @@ __device__ inline void solve4(double (&A)[4][5]) {
   }
 }
 
-__device__ inline Coef4s coef_4s(const double* rec, const BandIn& in, double mu_s) {
-  const double G = rec[S_G], mu0 = rec[S_MU], kap = rec[S_KB], G1 = rec[S_GINT1], G2 = rec[S_GINT2], LT = rec[S_LT];
-  const double om = in.r + in.t, rho = in.s;
-  const double R_dr0 = in.I_dr0 / (PI * mu0);  // :169
-  const double R_df0 = in.I_df0 / PI;          // :170
-  const double mu1 = 0.5 * mu_s * mu_s;        // :188
-  const double mu2 = 0.5 * (1 - mu_s * mu_s);
-  const double al = 0.5 * om * (1 - mu_s) * G2;  // :190
-  const double be = 0.5 * om * (1 - mu_s) * G1;  // :192
-  const double ga = 0.5 * om * mu_s * G1;        // :194
-  const double e1 = 0.25 * om * R_dr0 * mu_s;        // :196
-  const double e2 = 0.25 * om * R_dr0 * (1 - mu_s);  // :198
-  // index 0 <-> stream "2" (mu2, G2), index 1 <-> stream "1"
-  const double gd0 = G * e2 / mu2, gd1 = G * e1 / mu1;  // forcing of yd' (:83,:87)
-  const double w0 = G2 / (mu2 * mu2), w1 = G1 / (mu1 * mu1);
-  const double ba = w0 * (G2 - 2 * al), bb = -2 * w0 * be, bc = -2 * w1 * be, bd = w1 * (G1 - 2 * ga);
-  const double disc = sqrt((ba - bd) * (ba - bd) + 4 * bb * bc);
-  const double l1 = 0.5 * (ba + bd + disc);
-  const double l2 = (ba * bd - bb * bc) / l1;
-  // eigenvectors, each taken from the better-conditioned row
-  double v1x, v1y, v2x, v2y;
-  if (disc == 0.0) {
-    v1x = 1; v1y = 0; v2x = 0; v2y = 1;
-  } else if (ba >= bd) {
-    v1x = l1 - bd; v1y = bc;
-    v2x = bb;      v2y = l2 - ba;
-  } else {
-    v1x = bb;      v1y = l1 - ba;
-    v2x = l2 - bd; v2y = bc;
-  }
-  const double n0 = mu2 / G2, n1 = mu1 / G1;  // N = (M Kd)^-1
-  // particular solution p = P e^{-kappa x}:  (kappa^2 I - B) P = -2 M Kd gd
-  const double k2 = kap * kap;
-  const double r0 = -2 * (G2 / mu2) * gd0, r1 = -2 * (G1 / mu1) * gd1;
-  const double m00 = k2 - ba, m01 = -bb, m10 = -bc, m11 = k2 - bd;
-  const double idet = 1.0 / (m00 * m11 - m01 * m10);
-  const double P0 = (r0 * m11 - m01 * r1) * idet, P1 = (m00 * r1 - m10 * r0) * idet;
-  const double Pd0 = 0.5 * (P0 + kap * n0 * P0), Pd1 = 0.5 * (P1 + kap * n1 * P1);
-  const double Pu0 = 0.5 * (P0 - kap * n0 * P0), Pu1 = 0.5 * (P1 - kap * n1 * P1);
+struct Sch4s {
+  static constexpr int NARR = 4;
+  static constexpr bool SOIL = true;
+  double lam1, lam2;  // sqrt(|l1|), sqrt(|l2|)
+  bool osc;           // l2 < 0
+  double d[5], u[5];  // I_df_d / I_df_u = sum_k coef[k] * phi_k(x), phi = {E1, F1, phi3, phi4, e^{-kappa x}}
+  double I0, invmu, LT;
 
-  Coef4s k;
-  k.I0 = in.I_dr0;
-  k.osc = l2 < 0.0;
-  const double lam1 = sqrt(l1), lam2 = sqrt(fabs(l2));
-  k.lam1 = lam1;
-  k.lam2 = lam2;
-  // basis functions: phi1 = e^{-lam1 x}, phi2 = e^{-lam1 (L - x)},
-  //   real:  phi3 = e^{-lam2 x}, phi4 = e^{-lam2 (L - x)}      osc: phi3 = cos(lam2 x), phi4 = sin(lam2 x)
-  // yd, yu contribution vectors of each basis function at x = 0 and x = L
-  const double U1x = 0.5 * (v1x + lam1 * n0 * v1x), U1y = 0.5 * (v1y + lam1 * n1 * v1y);
-  const double W1x = 0.5 * (v1x - lam1 * n0 * v1x), W1y = 0.5 * (v1y - lam1 * n1 * v1y);
-  const double E1L = exp(-lam1 * LT);
-  // [basis][x=0 | x=L][yd | yu][component]
-  double Y[4][2][2][2];
-  // phi1: yd = U1 e^{-lam1 x}, yu = W1 e^{-lam1 x}
-  Y[0][0][0][0] = U1x;       Y[0][0][0][1] = U1y;       Y[0][0][1][0] = W1x;       Y[0][0][1][1] = W1y;
-  Y[0][1][0][0] = U1x * E1L; Y[0][1][0][1] = U1y * E1L; Y[0][1][1][0] = W1x * E1L; Y[0][1][1][1] = W1y * E1L;
-  // phi2: yd = W1 e^{-lam1 (L-x)}, yu = U1 e^{-lam1 (L-x)}
-  Y[1][0][0][0] = W1x * E1L; Y[1][0][0][1] = W1y * E1L; Y[1][0][1][0] = U1x * E1L; Y[1][0][1][1] = U1y * E1L;
-  Y[1][1][0][0] = W1x;       Y[1][1][0][1] = W1y;       Y[1][1][1][0] = U1x;       Y[1][1][1][1] = U1y;
-  // second pair
-  const double hx = 0.5 * v2x, hy = 0.5 * v2y;
-  const double qx = 0.5 * lam2 * n0 * v2x, qy = 0.5 * lam2 * n1 * v2y;  // (lam2/2) N v2
-  double cL = 0, sL = 0, E2L = 0;
-  if (k.osc) {
-    sincos(lam2 * LT, &sL, &cL);
-    // phi3 = cos: p = v c -> m = lam N v s : yd = h c + q s, yu = h c - q s
-    Y[2][0][0][0] = hx; Y[2][0][0][1] = hy; Y[2][0][1][0] = hx; Y[2][0][1][1] = hy;
-    Y[2][1][0][0] = hx * cL + qx * sL; Y[2][1][0][1] = hy * cL + qy * sL;
-    Y[2][1][1][0] = hx * cL - qx * sL; Y[2][1][1][1] = hy * cL - qy * sL;
-    // phi4 = sin: p = v s -> m = -lam N v c : yd = h s - q c, yu = h s + q c
-    Y[3][0][0][0] = -qx; Y[3][0][0][1] = -qy; Y[3][0][1][0] = qx; Y[3][0][1][1] = qy;
-    Y[3][1][0][0] = hx * sL - qx * cL; Y[3][1][0][1] = hy * sL - qy * cL;
-    Y[3][1][1][0] = hx * sL + qx * cL; Y[3][1][1][1] = hy * sL + qy * cL;
-  } else {
-    E2L = exp(-lam2 * LT);
-    const double U2x = hx + qx, U2y = hy + qy, W2x = hx - qx, W2y = hy - qy;
-    Y[2][0][0][0] = U2x;       Y[2][0][0][1] = U2y;       Y[2][0][1][0] = W2x;       Y[2][0][1][1] = W2y;
-    Y[2][1][0][0] = U2x * E2L; Y[2][1][0][1] = U2y * E2L; Y[2][1][1][0] = W2x * E2L; Y[2][1][1][1] = W2y * E2L;
-    Y[3][0][0][0] = W2x * E2L; Y[3][0][0][1] = W2y * E2L; Y[3][0][1][0] = U2x * E2L; Y[3][0][1][1] = U2y * E2L;
-    Y[3][1][0][0] = W2x;       Y[3][1][0][1] = W2y;       Y[3][1][1][0] = U2x;       Y[3][1][1][1] = U2y;
-  }
-  // boundary conditions
-  //   top    (x = 0): yd = R_df0 [1, 1]                                   (:110-116, both problems summed)
-  //   bottom (x = L): yu - rho (2 muv . yd + mu0 R_dr0 e^{-kappa L}) [1, 1] = 0     (:128-138)
-  const double eKL = exp(-kap * LT);
-  double A[4][5];
+  __device__ inline void init(const double* rec, const BandIn& in, const SolveArgs& a) {
+    const double mu_s = a.mu_s;
+    const double G = rec[S_G], mu0 = rec[S_MU], kap = rec[S_KB], G1 = rec[S_GINT1], G2 = rec[S_GINT2];
+    LT = rec[S_LT];
+    invmu = rec[S_INVMU];
+    const double om = in.r + in.t, rho = in.s;
+    const double R_dr0 = in.I_dr0 / (PI * mu0);  // :169
+    const double R_df0 = in.I_df0 / PI;          // :170
+    const double mu1 = 0.5 * mu_s * mu_s;        // :188
+    const double mu2 = 0.5 * (1 - mu_s * mu_s);
+    const double al = 0.5 * om * (1 - mu_s) * G2;  // :190
+    const double be = 0.5 * om * (1 - mu_s) * G1;  // :192
+    const double ga = 0.5 * om * mu_s * G1;        // :194
+    const double e1 = 0.25 * om * R_dr0 * mu_s;        // :196
+    const double e2 = 0.25 * om * R_dr0 * (1 - mu_s);  // :198
+    // index 0 <-> stream "2" (mu2, G2), index 1 <-> stream "1"
+    const double gd0 = G * e2 / mu2, gd1 = G * e1 / mu1;  // forcing of yd' (:83,:87)
+    const double w0 = G2 / (mu2 * mu2), w1 = G1 / (mu1 * mu1);
+    const double ba = w0 * (G2 - 2 * al), bb = -2 * w0 * be, bc = -2 * w1 * be, bd = w1 * (G1 - 2 * ga);
+    const double disc = sqrt((ba - bd) * (ba - bd) + 4 * bb * bc);
+    const double l1 = 0.5 * (ba + bd + disc);
+    const double l2 = (ba * bd - bb * bc) / l1;
+    // eigenvectors, each taken from the better-conditioned row
+    double v1x, v1y, v2x, v2y;
+    if (disc == 0.0) {
+      v1x = 1; v1y = 0; v2x = 0; v2y = 1;
+    } else if (ba >= bd) {
+      v1x = l1 - bd; v1y = bc;
+      v2x = bb;      v2y = l2 - ba;
+    } else {
+      v1x = bb;      v1y = l1 - ba;
+      v2x = l2 - bd; v2y = bc;
+    }
+    const double n0 = mu2 / G2, n1 = mu1 / G1;  // N = (M Kd)^-1
+    // particular solution p = P e^{-kappa x}:  (kappa^2 I - B) P = -2 M Kd gd
+    const double k2 = kap * kap;
+    const double r0 = -2 * (G2 / mu2) * gd0, r1 = -2 * (G1 / mu1) * gd1;
+    const double m00 = k2 - ba, m01 = -bb, m10 = -bc, m11 = k2 - bd;
+    const double idet = 1.0 / (m00 * m11 - m01 * m10);
+    const double P0 = (r0 * m11 - m01 * r1) * idet, P1 = (m00 * r1 - m10 * r0) * idet;
+    const double Pd0 = 0.5 * (P0 + kap * n0 * P0), Pd1 = 0.5 * (P1 + kap * n1 * P1);
+    const double Pu0 = 0.5 * (P0 - kap * n0 * P0), Pu1 = 0.5 * (P1 - kap * n1 * P1);
+
+    I0 = in.I_dr0;
+    osc = l2 < 0.0;
+    lam1 = sqrt(l1);
+    lam2 = sqrt(fabs(l2));
+    // basis functions: phi1 = e^{-lam1 x}, phi2 = e^{-lam1 (L - x)},
+    //   real:  phi3 = e^{-lam2 x}, phi4 = e^{-lam2 (L - x)}      osc: phi3 = cos(lam2 x), phi4 = sin(lam2 x)
+    const double U1x = 0.5 * (v1x + lam1 * n0 * v1x), U1y = 0.5 * (v1y + lam1 * n1 * v1y);
+    const double W1x = 0.5 * (v1x - lam1 * n0 * v1x), W1y = 0.5 * (v1y - lam1 * n1 * v1y);
+    const double E1L = exp(-lam1 * LT);
+    // yd, yu contribution of each basis function: [basis][x=0 | x=L][yd | yu][component]
+    double Y[4][2][2][2];
+    Y[0][0][0][0] = U1x;       Y[0][0][0][1] = U1y;       Y[0][0][1][0] = W1x;       Y[0][0][1][1] = W1y;
+    Y[0][1][0][0] = U1x * E1L; Y[0][1][0][1] = U1y * E1L; Y[0][1][1][0] = W1x * E1L; Y[0][1][1][1] = W1y * E1L;
+    Y[1][0][0][0] = W1x * E1L; Y[1][0][0][1] = W1y * E1L; Y[1][0][1][0] = U1x * E1L; Y[1][0][1][1] = U1y * E1L;
+    Y[1][1][0][0] = W1x;       Y[1][1][0][1] = W1y;       Y[1][1][1][0] = U1x;       Y[1][1][1][1] = U1y;
+    const double hx = 0.5 * v2x, hy = 0.5 * v2y;
+    const double qx = 0.5 * lam2 * n0 * v2x, qy = 0.5 * lam2 * n1 * v2y;  // (lam2/2) N v2
+    if (osc) {
+      double sL, cL;
+      sincos(lam2 * LT, &sL, &cL);
+      // phi3 = cos: p = v c -> m = lam N v s : yd = h c + q s, yu = h c - q s
+      Y[2][0][0][0] = hx; Y[2][0][0][1] = hy; Y[2][0][1][0] = hx; Y[2][0][1][1] = hy;
+      Y[2][1][0][0] = hx * cL + qx * sL; Y[2][1][0][1] = hy * cL + qy * sL;
+      Y[2][1][1][0] = hx * cL - qx * sL; Y[2][1][1][1] = hy * cL - qy * sL;
+      // phi4 = sin: p = v s -> m = -lam N v c : yd = h s - q c, yu = h s + q c
+      Y[3][0][0][0] = -qx; Y[3][0][0][1] = -qy; Y[3][0][1][0] = qx; Y[3][0][1][1] = qy;
+      Y[3][1][0][0] = hx * sL - qx * cL; Y[3][1][0][1] = hy * sL - qy * cL;
+      Y[3][1][1][0] = hx * sL + qx * cL; Y[3][1][1][1] = hy * sL + qy * cL;
+    } else {
+      const double E2L = exp(-lam2 * LT);
+      const double U2x = hx + qx, U2y = hy + qy, W2x = hx - qx, W2y = hy - qy;
+      Y[2][0][0][0] = U2x;       Y[2][0][0][1] = U2y;       Y[2][0][1][0] = W2x;       Y[2][0][1][1] = W2y;
+      Y[2][1][0][0] = U2x * E2L; Y[2][1][0][1] = U2y * E2L; Y[2][1][1][0] = W2x * E2L; Y[2][1][1][1] = W2y * E2L;
+      Y[3][0][0][0] = W2x * E2L; Y[3][0][0][1] = W2y * E2L; Y[3][0][1][0] = U2x * E2L; Y[3][0][1][1] = U2y * E2L;
+      Y[3][1][0][0] = W2x;       Y[3][1][0][1] = W2y;       Y[3][1][1][0] = U2x;       Y[3][1][1][1] = U2y;
+    }
+    // boundary conditions
+    //   top    (x = 0): yd = R_df0 [1, 1]                                   (:110-116, both problems summed)
+    //   bottom (x = L): yu - rho (2 muv . yd + mu0 R_dr0 e^{-kappa L}) [1, 1] = 0     (:128-138)
+    const double eKL = exp(-kap * LT);
+    double A[4][5];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    A[0][q] = Y[q][0][0][0];
-    A[1][q] = Y[q][0][0][1];
-    const double tq = 2 * rho * (mu2 * Y[q][1][0][0] + mu1 * Y[q][1][0][1]);
-    A[2][q] = Y[q][1][1][0] - tq;
-    A[3][q] = Y[q][1][1][1] - tq;
+    for (int q = 0; q < 4; ++q) {
+      A[0][q] = Y[q][0][0][0];
+      A[1][q] = Y[q][0][0][1];
+      const double tq = 2 * rho * (mu2 * Y[q][1][0][0] + mu1 * Y[q][1][0][1]);
+      A[2][q] = Y[q][1][1][0] - tq;
+      A[3][q] = Y[q][1][1][1] - tq;
+    }
+    A[0][4] = R_df0 - Pd0;
+    A[1][4] = R_df0 - Pd1;
+    const double tP = 2 * rho * (mu2 * Pd0 + mu1 * Pd1);
+    A[2][4] = eKL * (tP + rho * mu0 * R_dr0 - Pu0);
+    A[3][4] = eKL * (tP + rho * mu0 * R_dr0 - Pu1);
+    solve4(A);
+    // irradiance coefficients: I_df_d = 2 pi muv . yd, I_df_u = 2 pi muv . yu   (:246-249, :280-281)
+    const double tp = 2 * PI;
+    const double mU1 = tp * (mu2 * U1x + mu1 * U1y), mW1 = tp * (mu2 * W1x + mu1 * W1y);
+    d[0] = mU1 * A[0][4];
+    u[0] = mW1 * A[0][4];
+    d[1] = mW1 * A[1][4];
+    u[1] = mU1 * A[1][4];
+    const double mh = tp * (mu2 * hx + mu1 * hy), mq = tp * (mu2 * qx + mu1 * qy);
+    if (osc) {
+      // yd = a3 (h c + q s) + a4 (h s - q c);  yu = a3 (h c - q s) + a4 (h s + q c)
+      d[2] = mh * A[2][4] - mq * A[3][4];
+      d[3] = mq * A[2][4] + mh * A[3][4];
+      u[2] = mh * A[2][4] + mq * A[3][4];
+      u[3] = -mq * A[2][4] + mh * A[3][4];
+    } else {
+      d[2] = (mh + mq) * A[2][4];
+      u[2] = (mh - mq) * A[2][4];
+      d[3] = (mh - mq) * A[3][4];
+      u[3] = (mh + mq) * A[3][4];
+    }
+    d[4] = tp * (mu2 * Pd0 + mu1 * Pd1);
+    u[4] = tp * (mu2 * Pu0 + mu1 * Pu1);
   }
-  A[0][4] = R_df0 - Pd0;
-  A[1][4] = R_df0 - Pd1;
-  const double tP = 2 * rho * (mu2 * Pd0 + mu1 * Pd1);
-  A[2][4] = eKL * (tP + rho * mu0 * R_dr0 - Pu0);
-  A[3][4] = eKL * (tP + rho * mu0 * R_dr0 - Pu1);
-  solve4(A);
-  // irradiance coefficients: I_df_d = 2 pi muv . yd, I_df_u = 2 pi muv . yu   (:246-249, :280-281)
-  const double tp = 2 * PI;
-  const double mU1 = tp * (mu2 * U1x + mu1 * U1y), mW1 = tp * (mu2 * W1x + mu1 * W1y);
-  k.d[0] = mU1 * A[0][4];
-  k.u[0] = mW1 * A[0][4];
-  k.d[1] = mW1 * A[1][4];
-  k.u[1] = mU1 * A[1][4];
-  const double mh = tp * (mu2 * hx + mu1 * hy), mq = tp * (mu2 * qx + mu1 * qy);
-  if (k.osc) {
-    // yd = a3 (h c + q s) + a4 (h s - q c);  yu = a3 (h c - q s) + a4 (h s + q c)
-    k.d[2] = mh * A[2][4] - mq * A[3][4];
-    k.d[3] = mq * A[2][4] + mh * A[3][4];
-    k.u[2] = mh * A[2][4] + mq * A[3][4];
-    k.u[3] = -mq * A[2][4] + mh * A[3][4];
-  } else {
-    k.d[2] = (mh + mq) * A[2][4];
-    k.u[2] = (mh - mq) * A[2][4];
-    k.d[3] = (mh - mq) * A[3][4];
-    k.u[3] = (mh + mq) * A[3][4];
-  }
-  k.d[4] = tp * (mu2 * Pd0 + mu1 * Pd1);
-  k.u[4] = tp * (mu2 * Pu0 + mu1 * Pu1);
-  return k;
-}
 
-template <int VEC, bool USE_LDS>
-__global__ __launch_bounds__(BLOCK) void k_4s(SolveArgs a) {
+  __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) const {
+    const double x = rec[REC_HDR + j], eK = rec[REC_HDR + nz + j];
+    const double p1 = exp(-lam1 * x);
+    const double p2 = exp(-lam1 * (LT - x));
+    double p3, p4;
+    if (osc) {
+      sincos(lam2 * x, &p4, &p3);
+    } else {
+      p3 = exp(-lam2 * x);
+      p4 = exp(-lam2 * (LT - x));
+    }
+    const double dn = d[0] * p1 + d[1] * p2 + d[2] * p3 + d[3] * p4 + d[4] * eK;
+    const double up = u[0] * p1 + u[1] * p2 + u[2] * p3 + u[3] * p4 + u[4] * eK;
+    const double idr = I0 * eK;                      // :284
+    o[0] = idr;
+    o[1] = dn;
+    o[2] = up;
+    o[3] = idr * invmu + 2 * up + 2 * dn;            // :290
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// k_direct: lanes store their own band(s) per level (fallback for small nb)
+constexpr int DBLOCK = 256;
+
+template <class S, int VEC, bool USE_LDS>
+__global__ __launch_bounds__(DBLOCK) void k_direct(SolveArgs a) {
   extern __shared__ double lds[];
-  const Item it = locate<BLOCK, VEC>(a.ncol, a.nb);
-  const double* rec = stage_records<BLOCK, VEC, USE_LDS>(a, it, lds);
+  const Item it = locate<DBLOCK, VEC>(a.ncol, a.nb);
+  const double* rec = stage_records<DBLOCK, VEC, USE_LDS>(a, it, lds);
   if (!it.active) return;
-  BandIn in[VEC];
-  load_bands<VEC>(a, it, true, in);
-  Coef4s k[VEC];
+  S st[VEC];
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) k[v] = coef_4s(rec, in[v], a.mu_s);
-  const double invmu = rec[S_INVMU], LT = rec[S_LT];
+  for (int v = 0; v < VEC; ++v) st[v].init(rec, load_band(a, it.c, it.b + v, S::SOIL), a);
   const int nz = a.nz;
-  const double* lai = rec + REC_HDR;
-  const double* ekl = lai + nz;
   long long o = ((long long)it.c * nz) * a.nb + it.b;
   for (int j = 0; j < nz; ++j, o += a.nb) {
-    const double x = lai[j], eK = ekl[j];
-    double idr[VEC], dn[VEC], up[VEC], F[VEC];
+    double val[VEC][S::NARR];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const double p1 = exp(-k[v].lam1 * x);
-      const double p2 = exp(-k[v].lam1 * (LT - x));
-      double p3, p4;
-      if (k[v].osc) {
-        sincos(k[v].lam2 * x, &p4, &p3);
-      } else {
-        p3 = exp(-k[v].lam2 * x);
-        p4 = exp(-k[v].lam2 * (LT - x));
-      }
-      dn[v] = k[v].d[0] * p1 + k[v].d[1] * p2 + k[v].d[2] * p3 + k[v].d[3] * p4 + k[v].d[4] * eK;
-      up[v] = k[v].u[0] * p1 + k[v].u[1] * p2 + k[v].u[2] * p3 + k[v].u[3] * p4 + k[v].u[4] * eK;
-      idr[v] = k[v].I0 * eK;                               // :284
-      F[v] = idr[v] * invmu + 2 * up[v] + 2 * dn[v];       // :290
+    for (int v = 0; v < VEC; ++v) st[v].level(j, rec, nz, val[v]);
+#pragma unroll
+    for (int k = 0; k < S::NARR; ++k) {
+      double pk[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) pk[v] = val[v][k];
+      store_stream<VEC>(a.o[k] + o, pk);
     }
-    store_stream<VEC>(a.o[0] + o, idr);
-    store_stream<VEC>(a.o[1] + o, dn);
-    store_stream<VEC>(a.o[2] + o, up);
-    store_stream<VEC>(a.o[3] + o, F);
   }
 }
 
 // ------------------------------------------------------------------------------------------
-constexpr int MAX_LDS_BYTES = 64 * 1024;  // keep >= 2 workgroups per CU resident
+// k_tile: workgroup = CB whole columns; T levels staged in LDS, flushed as contiguous aligned runs
+typedef double d2 __attribute__((ext_vector_type(2)));
 
-template <int VEC, bool USE_LDS>
-int launch_vec(int scheme, const SolveArgs& a, size_t lds_bytes, hipStream_t s) {
-  const long long items = (long long)a.ncol * (a.nb / VEC);
-  const long long nblk = (items + BLOCK - 1) / BLOCK;
-  if (nblk > 0x7fffffffLL) return CRT_ERR_UNSUPPORTED;
-  dim3 grid((unsigned)nblk), block(BLOCK);
-  const size_t sh = USE_LDS ? lds_bytes : 0;
-  switch (scheme) {
-    case CRT_SCHEME_2S: hipLaunchKernelGGL((k_2s<VEC, USE_LDS>), grid, block, sh, s, a); break;
-    case CRT_SCHEME_4S: hipLaunchKernelGGL((k_4s<VEC, USE_LDS>), grid, block, sh, s, a); break;
-    case CRT_SCHEME_BL: hipLaunchKernelGGL((k_bl<VEC, USE_LDS>), grid, block, sh, s, a); break;
-    case CRT_SCHEME_G77: hipLaunchKernelGGL((k_g77<VEC, USE_LDS, false>), grid, block, sh, s, a); break;
-    case CRT_SCHEME_BF: hipLaunchKernelGGL((k_g77<VEC, USE_LDS, true>), grid, block, sh, s, a); break;
-    default: return CRT_ERR_BAD_ARG;
+struct TileCfg {
+  int CB;        // columns per workgroup
+  int T;         // levels per LDS tile
+  int rec_dbl;   // doubles reserved for the staged column records (CB * reclen, rounded up to even)
+  int flags;     // bit0: full __syncthreads() barriers (A/B aid)
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also emits s_waitcnt vmcnt(0), i.e.
+// every wave would drain its outstanding global stores (a full HBM write round trip) twice per tile;
+// the tile protocol only needs the LDS writes/reads of the other waves to have completed.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <class S, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {
+  extern __shared__ double lds[];
+  const int nb = a.nb, nz = a.nz, CB = cfg.CB, T = cfg.T;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int c0 = blockIdx.x * CB;
+  const int ncb = min(CB, a.ncol - c0);  // columns actually present in this workgroup
+  // stage the column records (contiguous in the workspace)
+  {
+    const double* src = a.ws + (long long)c0 * a.reclen;
+    const int n = ncb * a.reclen;
+    for (int i = tid; i < n; i += nthr) lds[i] = src[i];
   }
+  __syncthreads();
+  double* tile = lds + cfg.rec_dbl;  // [NARR][CB][T][nb]
+  const int cl = tid / nb, b = tid - cl * nb;
+  const bool active = cl < ncb;
+  const double* rec = lds + (active ? cl : 0) * a.reclen;
+  S st;
+  if (active) st.init(rec, load_band(a, c0 + cl, b, S::SOIL), a);
+  const int colrun = T * nb;  // doubles per (array, column) slot of the tile
+
+  for (int j0 = 0; j0 < nz; j0 += T) {
+    const int Tc = min(T, nz - j0);
+    if (active) {
+      double* tl = tile + cl * colrun + b;
+      for (int t = 0; t < Tc; ++t) {
+        double val[S::NARR];
+        st.level(j0 + t, rec, nz, val);
+#pragma unroll
+        for (int k = 0; k < S::NARR; ++k) tl[k * (CB * colrun) + t * nb] = val[k];
+      }
+    }
+    if (cfg.flags & 1) __syncthreads(); else lds_barrier();
+    // flush: per (array, column) one contiguous run of Tc * nb doubles
+    const int n = Tc * nb;
+    for (int k = 0; k < S::NARR; ++k) {
+      for (int q = 0; q < ncb; ++q) {
+        double* g = a.o[k] + ((long long)(c0 + q) * nz + j0) * nb;
+        const double* s = tile + k * (CB * colrun) + q * colrun;
+        const int mis = (int)((reinterpret_cast<uintptr_t>(g) >> 3) & 1);  // run starts on an odd double?
+        const int npair = (n - mis) >> 1;
+        if ((reinterpret_cast<uintptr_t>(s + mis) & 15) == 0) {
+          const d2* s2 = reinterpret_cast<const d2*>(s + mis);
+          d2* g2 = reinterpret_cast<d2*>(g + mis);
+          for (int i = tid; i < npair; i += nthr) g2[i] = s2[i];
+        } else {
+          d2* g2 = reinterpret_cast<d2*>(g + mis);
+          for (int i = tid; i < npair; i += nthr) {
+            d2 v;
+            v.x = s[mis + 2 * i];
+            v.y = s[mis + 2 * i + 1];
+            g2[i] = v;
+          }
+        }
+        if (tid == 0) {
+          if (mis) g[0] = s[0];
+          if ((n - mis) & 1) g[n - 1] = s[n - 1];
+        }
+      }
+    }
+    if (cfg.flags & 1) __syncthreads(); else lds_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+constexpr int MAX_DIRECT_LDS = 64 * 1024;
+// tunables (crt_hip_tune): [0] LDS bytes a tile may take per workgroup, [1] force T (0 = automatic),
+// [2] TileCfg.flags.  Measured on MI355X, 2s at 1e4 x 300 x 60 (tools/ab_tile.py, interleaved rounds):
+//   T=2 (not line aligned) 1.66 ms | T=4, 4 WG/CU 1.20 ms | T=8, 2 WG/CU 1.03 ms | T=12, 1 WG/CU 1.25 ms
+// -> take the longest line-aligned run that still leaves two workgroups resident per CU (160 KB LDS).
+int g_tune[8] = {78 * 1024, 0, 0, 0, 0, 0, 0, 0};
+
+int gcd(int x, int y) { return y ? gcd(y, x % y) : x; }
+
+template <class S>
+int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
+  done = false;
+  const int nb = a.nb;
+  if (nb < 64 || nb > 1024) return CRT_OK;
+  const int CB = nb <= 256 ? 256 / nb : 1;
+  const int nthr = CB > 1 ? 256 : ((nb + 63) / 64) * 64;
+  const int Ta = 16 / gcd(nb, 16);  // levels per line-aligned run
+  const size_t per_level = (size_t)S::NARR * CB * nb * sizeof(double);
+  const size_t target = (size_t)g_tune[0];
+  int T = Ta;
+  if (per_level * Ta > target) {
+    // aligned runs do not fit: fall back to the largest run that does (only its two end lines are partial)
+    T = (int)(target / per_level);
+    if (T < 2) return CRT_OK;
+  } else {
+    while (per_level * (T + Ta) <= target && T + Ta <= a.nz) T += Ta;
+  }
+  if (g_tune[1] > 0) T = g_tune[1];
+  if (T > a.nz) T = a.nz;
+  TileCfg cfg;
+  cfg.CB = CB;
+  cfg.T = T;
+  cfg.rec_dbl = (CB * a.reclen + 1) & ~1;
+  cfg.flags = g_tune[2];
+  const size_t sh = (cfg.rec_dbl + (size_t)S::NARR * CB * T * nb) * sizeof(double);
+  if (sh > 160 * 1024) return CRT_OK;
+  if (sh > 64 * 1024) {
+    const void* fn = nthr <= 256 ? (const void*)k_tile<S, 256> : nthr <= 512 ? (const void*)k_tile<S, 512> : (const void*)k_tile<S, 1024>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return CRT_ERR_LAUNCH;
+  }
+  const int grid = (a.ncol + CB - 1) / CB;
+  if (nthr <= 256)
+    hipLaunchKernelGGL((k_tile<S, 256>), dim3(grid), dim3(nthr), sh, s, a, cfg);
+  else if (nthr <= 512)
+    hipLaunchKernelGGL((k_tile<S, 512>), dim3(grid), dim3(nthr), sh, s, a, cfg);
+  else
+    hipLaunchKernelGGL((k_tile<S, 1024>), dim3(grid), dim3(nthr), sh, s, a, cfg);
+  done = true;
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+}
+
+template <class S, int VEC, bool USE_LDS>
+int launch_direct_v(const SolveArgs& a, size_t lds_bytes, hipStream_t s) {
+  const long long items = (long long)a.ncol * (a.nb / VEC);
+  const long long nblk = (items + DBLOCK - 1) / DBLOCK;
+  if (nblk > 0x7fffffffLL) return CRT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((k_direct<S, VEC, USE_LDS>), dim3((unsigned)nblk), dim3(DBLOCK), USE_LDS ? lds_bytes : 0, s, a);
+  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+}
+
+template <class S>
+int launch_scheme(const SolveArgs& a, hipStream_t s, int force) {
+  if (force != 1) {
+    bool done;
+    int st = launch_tile<S>(a, s, done);
+    if (st != CRT_OK || done) return st;
+  }
+  // two bands per lane (16-B stores) when rows keep 16-B alignment, else one
+  bool vec2 = (a.nb % 2 == 0) && (a.col_stride % 2 == 0);
+  for (int i = 0; i < S::NARR && vec2; ++i)
+    if (reinterpret_cast<uintptr_t>(a.o[i]) & 15) vec2 = false;
+  const int nbv = a.nb / (vec2 ? 2 : 1);
+  const long long cols_per_block = (DBLOCK - 1) / nbv + 2;
+  const size_t lds_bytes = (size_t)cols_per_block * a.reclen * sizeof(double);
+  const bool use_lds = lds_bytes <= (size_t)MAX_DIRECT_LDS;
+  if (vec2) return use_lds ? launch_direct_v<S, 2, true>(a, lds_bytes, s) : launch_direct_v<S, 2, false>(a, lds_bytes, s);
+  return use_lds ? launch_direct_v<S, 1, true>(a, lds_bytes, s) : launch_direct_v<S, 1, false>(a, lds_bytes, s);
 }
 
 }  // namespace
 
-int launch_closed(int scheme, const SolveArgs& a, hipStream_t s) {
-  // two bands per lane (16-B stores) when rows keep 16-B alignment, else one
-  bool vec2 = (a.nb % 2 == 0) && (a.col_stride % 2 == 0);
-  for (int i = 0; i < 7 && vec2; ++i)
-    if (a.o[i] && (reinterpret_cast<uintptr_t>(a.o[i]) & 15)) vec2 = false;
-  const int vec = vec2 ? 2 : 1;
-  const int nbv = a.nb / vec;
-  const long long cols_per_block = (BLOCK - 1) / nbv + 2;
-  const size_t lds_bytes = (size_t)cols_per_block * a.reclen * sizeof(double);
-  const bool use_lds = lds_bytes <= (size_t)MAX_LDS_BYTES;
-  if (vec2) return use_lds ? launch_vec<2, true>(scheme, a, lds_bytes, s) : launch_vec<2, false>(scheme, a, lds_bytes, s);
-  return use_lds ? launch_vec<1, true>(scheme, a, lds_bytes, s) : launch_vec<1, false>(scheme, a, lds_bytes, s);
+void tune_closed(int key, int value) {
+  if (key >= 0 && key < 8) g_tune[key] = value;
+}
+
+// force: 0 = pick (tile when it applies), 1 = direct-store kernel (kept selectable for A/B measurements)
+int launch_closed(int scheme, const SolveArgs& a, hipStream_t s, int force) {
+  switch (scheme) {
+    case CRT_SCHEME_2S: return launch_scheme<Sch2s>(a, s, force);
+    case CRT_SCHEME_4S: return launch_scheme<Sch4s>(a, s, force);
+    case CRT_SCHEME_BL: return launch_scheme<SchBl>(a, s, force);
+    case CRT_SCHEME_G77: return launch_scheme<SchG77<false>>(a, s, force);
+    case CRT_SCHEME_BF: return launch_scheme<SchG77<true>>(a, s, force);
+    default: return CRT_ERR_BAD_ARG;
+  }
 }
 
 }  // namespace crt

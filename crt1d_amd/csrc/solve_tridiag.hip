@@ -240,7 +240,8 @@ int set_lds_limit(K kern, size_t bytes) {
 
 }  // namespace
 
-int launch_tridiag(int scheme, const SolveArgs& a, hipStream_t s) {
+int launch_tridiag(int scheme, const SolveArgs& a, hipStream_t s, int force) {
+  (void)force;
   const long long items = (long long)a.ncol * a.nb;
   const long long nblk = (items + TB - 1) / TB;
   if (nblk > 0x7fffffffLL) return CRT_ERR_UNSUPPORTED;

@@ -103,6 +103,8 @@ typedef struct crt_bands {
 #define CRT_FLAG_SKIP_PRECOMPUTE 1 /* workspace already holds the column records of an earlier call with the
                                       same scheme/columns/options (only the spectra changed): skip kernel K0 */
 #define CRT_FLAG_PRECOMPUTE_ONLY 2 /* run K0 only (fills the workspace), no solve kernel */
+#define CRT_FLAG_DIRECT_STORES 4   /* measurement aid: use the direct-store solve kernel even where the LDS-tiled,
+                                      line-aligned one applies (same results, different store pattern) */
 
 typedef struct crt_options {
   double mu_s;            /* 4s: cosine of the dividing angle, default 0.501 (_solve_4s.py:9) */
@@ -152,6 +154,9 @@ int crt_hip_bf_f64(const crt_columns*, const crt_bands*, const crt_options*, con
 int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, const double* I_dr, const double* I_df_d,
                                const double* I_df_u, const double* band_w, int32_t ngroup, double* aI, double* aI_sl,
                                double* aI_sh, double* totals, crt_stream_t stream);
+
+/* measurement aid (not for production use): override kernel-selection heuristics, see solve_closed.hip */
+void crt_hip_tune(int key, int value);
 
 /* bandwidth probes used by bench.py to report a measured HBM ceiling next to the 8 TB/s spec */
 int crt_hip_probe_fill_f64(double* dst, size_t n, double value, crt_stream_t stream);
