@@ -78,6 +78,7 @@ EXPORTS = [
     "crt_hip_g77_f64",
     "crt_hip_bf_f64",
     "crt_hip_absorb_bandsum_f64",
+    "crt_hip_absorb_f64",
     "crt_hip_tune",
     "crt_hip_probe_fill_f64",
     "crt_hip_probe_copy_f64",
@@ -131,6 +132,8 @@ def load():
     lib.crt_hip_absorb_bandsum_f64.argtypes = [
         ctypes.POINTER(CrtColumns), ctypes.POINTER(CrtBands), _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp,
     ]
+    lib.crt_hip_absorb_f64.restype = ctypes.c_int
+    lib.crt_hip_absorb_f64.argtypes = [ctypes.POINTER(CrtColumns), ctypes.POINTER(CrtBands), _vp, _vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp]
     lib.crt_hip_tune.restype = None
     lib.crt_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.crt_hip_probe_fill_f64.restype = ctypes.c_int

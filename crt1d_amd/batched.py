@@ -258,3 +258,27 @@ def absorb_bandsum(cols: Columns, bands: Bands, sol, band_w):
         )
     _lib.check(st, "crt_hip_absorb_bandsum_f64")
     return {"aI": aI, "aI_sl": aI_sl, "aI_sh": aI_sh, "totals": totals}
+
+
+ABSORPTION_KEYS = ("aI", "aI_df", "aI_dr", "aI_sh", "aI_sl", "aI_df_sl", "aI_df_sh")  # model.py:637-647
+
+
+def absorb(cols: Columns, bands: Bands, sol):
+    """Per-band layerwise absorption: the reference's ``Model.absorption`` dict (``model.py:573-647``), batched.
+    Returns the seven ``(ncol, nz-1, nb)`` arrays plus ``laim``, ``f_slm`` ``(ncol, nz-1)``."""
+    lib = _lib.load()
+    ncol, nz, nb = cols.ncol, cols.nz, bands.nb
+    dev = cols.device
+    out = {k: torch.empty((ncol, nz - 1, nb), dtype=torch.float64, device=dev) for k in ABSORPTION_KEYS}
+    laim = torch.empty((ncol, nz - 1), dtype=torch.float64, device=dev)
+    f_slm = torch.empty_like(laim)
+    ptrs = (ctypes.c_void_p * 7)(*[out[k].data_ptr() for k in ABSORPTION_KEYS])
+    c, b = cols.c_struct(), bands.c_struct(ncol)
+    with torch.cuda.device(dev):
+        st = lib.crt_hip_absorb_f64(ctypes.byref(c), ctypes.byref(b), sol["I_dr"].data_ptr(), sol["I_df_d"].data_ptr(),
+                                    sol["I_df_u"].data_ptr(), ptrs, laim.data_ptr(), f_slm.data_ptr(),
+                                    torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(st, "crt_hip_absorb_f64")
+    out["laim"] = laim
+    out["f_slm"] = f_slm
+    return out

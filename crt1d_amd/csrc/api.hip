@@ -117,6 +117,68 @@ __global__ __launch_bounds__(EB) void k_absorb_bandsum(EpiArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-band layer absorption, model.py:573-647: the seven (nz-1, nb) arrays + laim, f_slm of the reference's
+// `Model.absorption` dict.  One workgroup per column, lanes over bands, previous level kept in registers.
+struct AbsArgs {
+  int ncol, nb, nz;
+  long long col_stride;
+  const double* psi;
+  const double* lai;
+  const int32_t* g_kind;
+  const double* g_param;
+  const double* g_at_psi;
+  const double* leaf_r;
+  const double* leaf_t;
+  const double* I_dr;
+  const double* I_df_d;
+  const double* I_df_u;
+  double* o[7];  // aI, aI_df, aI_dr, aI_sh, aI_sl, aI_df_sl, aI_df_sh
+  double* laim;
+  double* f_slm;
+};
+
+__global__ __launch_bounds__(256) void k_absorb(AbsArgs a) {
+  const int c = blockIdx.x;
+  const int nz = a.nz, nb = a.nb;
+  const double psi = a.psi[c];
+  const int kind = a.g_kind[c];
+  const double G = (kind == CRT_G_TABLE) ? a.g_at_psi[c] : G_closed(kind, a.g_param ? a.g_param[c] : 0.0, cos(psi), sin(psi));
+  const double Kb = G / cos(psi);
+  const double* lai = a.lai + (long long)c * nz;
+  const long long cb = (long long)c * nz * nb;
+  const long long cm = (long long)c * (nz - 1) * nb;
+  for (int b = threadIdx.x; b < nb; b += 256) {
+    const double leaf_a = 1 - (a.leaf_r[(long long)c * a.col_stride + b] + a.leaf_t[(long long)c * a.col_stride + b]);  // :584
+    double r0 = a.I_dr[cb + b], d0 = a.I_df_d[cb + b], u0 = a.I_df_u[cb + b];
+    for (int k = 0; k < nz - 1; ++k) {
+      const long long i1 = cb + (long long)(k + 1) * nb + b;
+      const double r1 = a.I_dr[i1], d1 = a.I_df_d[i1], u1 = a.I_df_u[i1];
+      const double dl = lai[k] - lai[k + 1];
+      const double fsl = exp(-Kb * ((lai[k] + lai[k + 1]) / 2));   // :601-602
+      const double av = r1 - r0 + d1 - d0 + u0 - u1;               // :609
+      const double adr = r1 * (1 - exp(-Kb * dl)) * leaf_a;        // :617-621
+      const double adf = av - adr;                                 // :628
+      const double adfsl = adf * fsl, adfsh = adf * (1 - fsl);     // :631-632
+      const long long o = cm + (long long)k * nb + b;
+      a.o[0][o] = av;
+      a.o[1][o] = adf;
+      a.o[2][o] = adr;
+      a.o[3][o] = adfsh;
+      a.o[4][o] = adfsl + adr;
+      a.o[5][o] = adfsl;
+      a.o[6][o] = adfsh;
+      if (b == 0) {
+        a.laim[(long long)c * (nz - 1) + k] = (lai[k] + lai[k + 1]) / 2;
+        a.f_slm[(long long)c * (nz - 1) + k] = fsl;
+      }
+      r0 = r1;
+      d0 = d1;
+      u0 = u1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // bandwidth probes: plain 16-B-per-lane streaming fill / copy, grid-stride
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -284,6 +346,36 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
   a.aI_sh = aI_sh;
   a.totals = totals;
   hipLaunchKernelGGL(k_absorb_bandsum, dim3(a.ncol), dim3(EB), 0, static_cast<hipStream_t>(stream), a);
+  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+}
+
+int crt_hip_absorb_f64(const crt_columns* cols, const crt_bands* bands, const double* I_dr, const double* I_df_d,
+                       const double* I_df_u, double* const* out7, double* laim, double* f_slm, crt_stream_t stream) {
+  if (!cols || !bands || !I_dr || !I_df_d || !I_df_u || !out7 || !laim || !f_slm) return CRT_ERR_BAD_ARG;
+  if (cols->ncol <= 0 || cols->nz < 2 || bands->nb <= 0) return CRT_ERR_BAD_ARG;
+  if (!cols->psi || !cols->lai || !cols->g_kind || !bands->leaf_r || !bands->leaf_t) return CRT_ERR_BAD_ARG;
+  AbsArgs a;
+  a.ncol = cols->ncol;
+  a.nb = bands->nb;
+  a.nz = cols->nz;
+  a.col_stride = bands->col_stride;
+  a.psi = cols->psi;
+  a.lai = cols->lai;
+  a.g_kind = cols->g_kind;
+  a.g_param = cols->g_param;
+  a.g_at_psi = cols->g_at_psi;
+  a.leaf_r = bands->leaf_r;
+  a.leaf_t = bands->leaf_t;
+  a.I_dr = I_dr;
+  a.I_df_d = I_df_d;
+  a.I_df_u = I_df_u;
+  for (int i = 0; i < 7; ++i) {
+    if (!out7[i]) return CRT_ERR_BAD_ARG;
+    a.o[i] = out7[i];
+  }
+  a.laim = laim;
+  a.f_slm = f_slm;
+  hipLaunchKernelGGL(k_absorb, dim3(a.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 

@@ -1,0 +1,94 @@
+"""
+Multi-GPU: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm).
+
+The (column x band) solves are independent units; nothing is exchanged inside a solve.
+
+* ``partition="column"`` (preferred): rank r owns a contiguous block of columns, all bands.  Zero
+  communication -- integrated quantities are per column and stay on the owning rank.
+* ``partition="band"``: rank r owns a contiguous block of bands of ALL columns (300 bands on 8 ranks ->
+  38,38,38,38,37,37,37,37).  The per-column precompute is replicated.  The only cross-band coupling is the
+  spectral integral ``sum_wl w X`` (``crt1d/diagnostics.py:81``), so each rank forms partial band sums of the
+  layer absorption and of the energy-balance terms and ONE all-reduce(sum) of one packed fp64 buffer
+  completes them (all band groups in a single call; xGMI rings are per-link bound, so fewer/larger messages).
+  Ratios (reflectance = reflected / incoming) are formed after the reduce.
+
+The compute functions are injectable so that the sharding/reduction logic is testable with ``gloo`` on CPU
+(tests pass oracle-backed functions); the defaults are the HIP path.
+"""
+
+import torch
+import torch.distributed as dist
+
+
+def block_range(n, rank, world):
+    """Contiguous balanced block [lo, hi) of ``n`` items for ``rank`` of ``world`` (first ``n % world`` ranks get one more)."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def _default_fns():
+    from . import batched
+
+    return batched.solve, batched.absorb_bandsum
+
+
+def solve_sharded(scheme, cols, bands, band_w, *, partition="column", group=None, solve_fn=None, epilogue_fn=None, **opts):
+    """Solve this rank's shard and return spectrally integrated results.
+
+    ``cols`` / ``bands``: the FULL problem (objects with ``.ncol``, ``.nb``, ``.slice(lo, hi)``, ``.band_slice(lo, hi)``;
+    :class:`crt1d_amd.batched.Columns` / ``Bands`` on the GPU).  ``band_w``: ``(ngroup, nb)`` integration weights.
+
+    Returns a dict with
+      ``aI, aI_sl, aI_sh``  ``(ncol_local, nz-1, ngroup)``, ``totals (ncol_local, ngroup, 4)``, ``reflectance (ncol_local, ngroup)``,
+      ``columns`` = (lo, hi) of the columns these rows describe, and ``profiles`` = this rank's full (unreduced) solver outputs.
+    With ``partition="band"`` every rank ends up with the complete integrated result for all columns.
+    """
+    if solve_fn is None or epilogue_fn is None:
+        s, e = _default_fns()
+        solve_fn = solve_fn or s
+        epilogue_fn = epilogue_fn or e
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if partition == "column":
+        lo, hi = block_range(cols.ncol, rank, world)
+        c, b = cols.slice(lo, hi), bands.slice(lo, hi)
+        sol = solve_fn(scheme, c, b, **opts)
+        res = epilogue_fn(c, b, sol, band_w)
+        col_range = (lo, hi)
+    elif partition == "band":
+        lo, hi = block_range(bands.nb, rank, world)
+        b = bands.band_slice(lo, hi)
+        sol = solve_fn(scheme, cols, b, **opts)
+        res = epilogue_fn(cols, b, sol, band_w[:, lo:hi].contiguous())
+        if world > 1:
+            keys = ("aI", "aI_sl", "aI_sh", "totals")
+            flat = torch.cat([res[k].reshape(-1) for k in keys])  # one packed message
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            off = 0
+            for k in keys:
+                n = res[k].numel()
+                res[k] = flat[off:off + n].view_as(res[k])
+                off += n
+        col_range = (0, cols.ncol)
+    else:
+        raise ValueError("partition must be 'column' or 'band'")
+    tot = res["totals"]
+    res["reflectance"] = tot[..., 1] / tot[..., 0]  # I_df_u[top] / I_d[top]  (diagnostics.py:510-511)
+    res["columns"] = col_range
+    res["profiles"] = sol
+    return res
+
+
+def gather_columns(local, ncol, group=None):
+    """All-gather per-column integrated results of a column-partitioned run into full ``(ncol, ...)`` tensors."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    sizes = [block_range(ncol, r, world)[1] - block_range(ncol, r, world)[0] for r in range(world)]
+    m = max(sizes)  # all_gather wants equal shapes: pad the (at most one row) shorter blocks
+    padded = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)

@@ -155,6 +155,13 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
                                const double* I_df_u, const double* band_w, int32_t ngroup, double* aI, double* aI_sl,
                                double* aI_sh, double* totals, crt_stream_t stream);
 
+/*
+ * Per-band layer absorption (model.py:573-647 `_calc_absorption`): out7 = {aI, aI_df, aI_dr, aI_sh, aI_sl, aI_df_sl,
+ * aI_df_sh}, each [ncol][nz-1][nb]; laim, f_slm [ncol][nz-1].
+ */
+int crt_hip_absorb_f64(const crt_columns* cols, const crt_bands* bands, const double* I_dr, const double* I_df_d,
+                       const double* I_df_u, double* const* out7, double* laim, double* f_slm, crt_stream_t stream);
+
 /* measurement aid (not for production use): override kernel-selection heuristics, see solve_closed.hip */
 void crt_hip_tune(int key, int value);
 

@@ -253,6 +253,16 @@ def main():
         p = default_case_inputs(la, lar)
     if want("g1"):
         g1(la, lar, sol, out)
+    if want("default-data"):
+        # spectral inputs of the default case as a small packaged data file for crt1d_amd.cases
+        pd_ = default_case_inputs(la, lar)
+        path = REPO / "crt1d_amd" / "data" / "default_spectra.npz"
+        np.savez_compressed(
+            path, **{k: np.asarray(pd_[k]) for k in ("wl", "dwl", "leaf_t", "leaf_r", "soil_r", "I_dr0_all", "I_df0_all")},
+            meta=np.array("default spectra of crt1d (ideal green leaf + SPCTRAL2 default spectrum + 2-value soil), NaN bands "
+                          "dropped; derived by oracle/gen_golden.py from the reference's packaged CSV files"),
+        )
+        print("wrote", path)
     if want("g5"):
         g5(la, lar, sol, out, p)
     if want("g2"):

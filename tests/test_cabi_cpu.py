@@ -1,0 +1,115 @@
+"""CPU: the C-ABI shared library loads without a GPU and exports every symbol include/crt1d_hip.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from crt1d_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "crt1d_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(crt_hip_\w+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from crt1d_amd import _lib
+
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/crt1d_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == names  # the Python binding list tracks the header
+
+
+def test_struct_layouts_match_header(lib):
+    from crt1d_amd import _lib
+
+    assert ctypes.sizeof(_lib.CrtColumns) == 8 + 7 * 8
+    assert ctypes.sizeof(_lib.CrtBands) == 8 + 8 + 5 * 8
+    assert ctypes.sizeof(_lib.CrtOptions) == 16
+    assert ctypes.sizeof(_lib.CrtOutputs) == 7 * 8
+
+
+def test_host_only_entry_points(lib):
+    from crt1d_amd import _lib
+
+    assert lib.crt_hip_abi_version() == 1
+    assert _lib.strerror(0) == "ok" and "workspace" in _lib.strerror(_lib.CRT_ERR_WORKSPACE)
+    # record = 16-double header + nvec * nz
+    assert lib.crt_hip_workspace_bytes(_lib.SCHEME_IDS["2s"], 10, 60) == 10 * (16 + 2 * 60) * 8
+    assert lib.crt_hip_workspace_bytes(_lib.SCHEME_IDS["n79"], 10, 60) == 10 * (16 + 6 * 60) * 8
+    assert lib.crt_hip_workspace_bytes(99, 10, 60) == 0
+    nodes = _lib.quad_nodes(0.501)
+    assert nodes.shape == (_lib.NQ,)
+    assert np.all((nodes > 0) & (nodes < np.pi / 2))
+    # graded rule: 6 panels x 16 nodes, finest panel next to pi/2
+    assert np.pi / 2 - nodes[:16].max() < (np.pi / 2) * 0.25**5
+    g4 = nodes[96:128]
+    assert np.all(g4[:16] > np.arccos(0.501)) and np.all(g4[16:] < np.arccos(0.501))
+    np.testing.assert_allclose(np.rad2deg(nodes[128:]), np.arange(5, 90, 10))
+    with pytest.raises(ValueError):
+        _lib.quad_nodes(1.5)
+
+
+def test_quadrature_nodes_integrate_tau_d(lib):
+    """The device's fixed tau_d rule, rebuilt on the host from the exported nodes, against a closed form:
+    horizontal leaves, K_b = 1  ->  tau_d(L) = exp(-L) exactly; spherical -> 2 E_3(L/2)."""
+    from numpy.polynomial.legendre import leggauss
+    from scipy.special import expn
+
+    from crt1d_amd import _lib
+
+    psi = _lib.quad_nodes(0.501)[:96]
+    x, w = leggauss(16)
+    T = np.pi / 2
+    edges = [0.0] + [T * 0.25**k for k in range(5, -1, -1)]
+    wts = np.concatenate([w * (b - a) / 2 for a, b in zip(edges[:-1], edges[1:])])
+    for L in (1e-3, 0.0678, 1.0, 8.0):
+        td = np.sum(2 * wts * np.exp(-0.5 / np.cos(psi) * L) * np.sin(psi) * np.cos(psi))
+        assert abs(td - 2 * expn(3, 0.5 * L)) / (2 * expn(3, 0.5 * L)) < 5e-13
+
+
+def test_validation_without_gpu(lib):
+    """Argument validation happens before any launch, so it can be exercised on the CPU."""
+    from crt1d_amd import _lib
+
+    c, b, o, out = _lib.CrtColumns(), _lib.CrtBands(), _lib.CrtOptions(0.501, 0, 0), _lib.CrtOutputs()
+    assert lib.crt_hip_2s_f64(ctypes.byref(c), ctypes.byref(b), ctypes.byref(o), ctypes.byref(out), None, 0, None) == _lib.CRT_ERR_BAD_ARG
+    assert lib.crt_hip_solve_f64(42, ctypes.byref(c), ctypes.byref(b), ctypes.byref(o), ctypes.byref(out), None, 0, None) == _lib.CRT_ERR_BAD_ARG
+    with pytest.raises(ValueError):
+        _lib.check(_lib.CRT_ERR_BAD_ARG, "x")
+    with pytest.raises(AssertionError):
+        _lib.check(_lib.CRT_ERR_SHAPE, "x")
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.CRT_ERR_LAUNCH, "x")
+
+
+def test_product_does_not_import_the_oracle():
+    """The product path must never route through the oracle (or any CPU fallback)."""
+    import subprocess
+    import sys
+
+    code = "import sys, crt1d_amd, crt1d_amd.batched, crt1d_amd.solvers, crt1d_amd.model, crt1d_amd.dist; " \
+           "print(any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules))"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert r.stdout.strip() == "False", r.stdout + r.stderr
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "crt1d_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

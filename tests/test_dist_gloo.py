@@ -1,0 +1,124 @@
+"""CPU, world_size 2, gloo: the sharding + final-reduce logic of crt1d_amd.dist with an oracle-backed compute
+function injected (the HIP kernels need a GPU; the partition / packing / all-reduce / gather code is the same)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+NCOL, NB, NZ = 7, 9, 12  # deliberately not divisible by 2
+
+
+class HostCols:
+    def __init__(self, d):
+        self.d = d
+        self.ncol, self.nz = d["lai"].shape
+
+    def slice(self, lo, hi):
+        return HostCols({k: (v[lo:hi] if isinstance(v, np.ndarray) and v.shape[:1] == (self.ncol,) else v) for k, v in self.d.items()})
+
+
+class HostBands:
+    keys = ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r")
+
+    def __init__(self, d):
+        self.d = {k: d[k] for k in self.keys}
+        self.nb = d["I_dr0"].shape[1]
+
+    def slice(self, lo, hi):
+        return HostBands({k: v[lo:hi] for k, v in self.d.items()})
+
+    def band_slice(self, lo, hi):
+        return HostBands({k: np.ascontiguousarray(v[:, lo:hi]) for k, v in self.d.items()})
+
+
+def _oracle_fns():
+    from oracle import crt_oracle as O
+
+    def ocols(c):
+        d = c.d
+        return O.Columns(d["psi"], d["lai"], mla=d["mla"], g_kind=d["g_kind"], g_param=d["g_param"])
+
+    def solve_fn(scheme, cols, bands, **opts):
+        kw = dict(bands.d)
+        if scheme == "bl":
+            kw.pop("soil_r")
+        return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in O.SOLVERS[scheme](ocols(cols), **kw, **opts).items()}
+
+    def epilogue_fn(cols, bands, sol, band_w):
+        out = {k: sol[k].numpy() for k in ("I_dr", "I_df_d", "I_df_u")}
+        ab = O.calc_absorption(ocols(cols), out, leaf_r=bands.d["leaf_r"], leaf_t=bands.d["leaf_t"])
+        w = band_w.numpy().T  # (nb, ng)
+        tot = np.stack([(out["I_dr"][:, -1] + out["I_df_d"][:, -1]) @ w, out["I_df_u"][:, -1] @ w,
+                        (out["I_dr"][:, 0] + out["I_df_d"][:, 0]) @ w, out["I_df_u"][:, 0] @ w], axis=-1)
+        return {"aI": torch.from_numpy(ab["aI"] @ w), "aI_sl": torch.from_numpy(ab["aI_sl"] @ w),
+                "aI_sh": torch.from_numpy(ab["aI_sh"] @ w), "totals": torch.from_numpy(tot)}
+
+    return solve_fn, epilogue_fn
+
+
+def _problem():
+    from crt1d_amd import spectra, synth
+
+    d = synth.make_columns(NCOL, NB, NZ, seed=21)
+    return d, torch.from_numpy(spectra.band_weights(d["wle"]))
+
+
+def _worker(rank, world, port, scheme, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from crt1d_amd.dist import gather_columns, solve_sharded
+
+        d, bw = _problem()
+        solve_fn, epi = _oracle_fns()
+        cols, bands = HostCols(d), HostBands(d)
+        rb = solve_sharded(scheme, cols, bands, bw, partition="band", solve_fn=solve_fn, epilogue_fn=epi)
+        rc = solve_sharded(scheme, cols, bands, bw, partition="column", solve_fn=solve_fn, epilogue_fn=epi)
+        full_c = {k: gather_columns(rc[k], NCOL) for k in ("aI", "aI_sl", "aI_sh", "totals", "reflectance")}
+        q.put((rank, {k: rb[k].numpy() for k in full_c}, {k: v.numpy() for k, v in full_c.items()}, rc["columns"],
+               tuple(rb["profiles"]["I_dr"].shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("scheme", ["2s", "n79"])
+def test_band_and_column_partition_world2(scheme):
+    from crt1d_amd.dist import solve_sharded
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, scheme, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference of the same pipeline
+    d, bw = _problem()
+    solve_fn, epi = _oracle_fns()
+    ref = solve_sharded(scheme, HostCols(d), HostBands(d), bw, partition="column", solve_fn=solve_fn, epilogue_fn=epi)
+    for rank, band_res, col_res, col_range, prof_shape in got:
+        assert col_range == ((0, 4) if rank == 0 else (4, 7))
+        assert prof_shape == (NCOL, NZ, 5 if rank == 0 else 4)  # 9 bands -> 5 + 4
+        for k in ("aI", "aI_sl", "aI_sh", "totals", "reflectance"):
+            # all-reduce order differs from a sequential sum: compare at 1e-12, not bitwise
+            np.testing.assert_allclose(band_res[k], ref[k].numpy(), rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(col_res[k], ref[k].numpy(), rtol=1e-14, atol=0)
+    # energy: incoming - reflected - soil-absorbed == canopy absorption (solar band group = index 2)
+    tot = ref["totals"].numpy()[:, 2]
+    canopy = ref["aI"].numpy()[:, :, 2].sum(axis=1)
+    np.testing.assert_allclose(tot[:, 0] - tot[:, 1] - (tot[:, 2] - tot[:, 3]), canopy, rtol=1e-10)
