@@ -379,7 +379,12 @@ int crt_hip_absorb_f64(const crt_columns* cols, const crt_bands* bands, const do
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 
-void crt_hip_tune(int key, int value) { tune_closed(key, value); }
+void crt_hip_tune(int key, int value) {
+  if (key >= 8)
+    tune_tridiag(key - 8, value);
+  else
+    tune_closed(key, value);
+}
 
 int crt_hip_probe_fill_f64(double* dst, size_t n, double value, crt_stream_t stream) {
   if (!dst || n == 0 || (n & 1) || (reinterpret_cast<uintptr_t>(dst) & 15)) return CRT_ERR_BAD_ARG;

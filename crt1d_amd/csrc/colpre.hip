@@ -174,6 +174,15 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
     hdr[S_G] = G;
     hdr[S_INVMU] = 1.0 / cs;
     hdr[S_LT] = lai[0];
+    {
+      // uniform-dlai detection (lets the solve kernels advance exponentials by recurrence)
+      const double dl = (lai[0] - lai[nz - 1]) / (nz - 1);
+      const double tol = 4.0 * 2.220446049250313e-16 * fabs(lai[0]);
+      bool unif = dl > 0.0;
+      for (int j = 0; j + 1 < nz; ++j) unif = unif && fabs((lai[j] - lai[j + 1]) - dl) <= tol;
+      hdr[S_UNIF] = unif ? 1.0 : 0.0;
+      hdr[S_DL] = dl;
+    }
     if (a.scheme == CRT_SCHEME_2S) {
       double s = 0.0;
       for (int q = 0; q < NQT; ++q) s += pmb[q];  // fixed order: bitwise reproducible

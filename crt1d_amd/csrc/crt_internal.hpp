@@ -31,6 +31,8 @@ enum RecScalar {
   S_COS2 = 9,   // cos^2(radians(mla))                 _solve_2s.py:28,68
   S_LT = 10,    // lai[0], total LAI
   S_INVMU = 11, // 1/cos(psi)
+  S_UNIF = 12,  // 1.0 when every dlai_j equals S_DL to within 4 ulp of LAI (all reference LAI generators), else 0.0
+  S_DL = 13,    // (lai[0] - lai[nz-1]) / (nz - 1)
   REC_HDR = 16
 };
 
@@ -179,12 +181,28 @@ __device__ inline void store_stream(double* p, const double (&v)[VEC]) {
   }
 }
 
+// 1/x for normal, positive-or-negative x well inside the exponent range: hardware seed + two Newton steps
+// (<= 1 ulp; skips the scaling / fix-up of the IEEE division sequence, ~5 instructions instead of ~10)
+__device__ inline double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// Levels at which the per-level exponentials are re-evaluated exactly when a column has uniform dlai; in between
+// they advance by one multiplication (e^{-h(L - dl)} = e^{-hL} e^{h dl}).  At most 7 products since the last exact
+// value -> <= 8 ulp; the rule depends on j only, so every kernel variant produces the same bits.
+__device__ inline bool exact_level(int j) { return (j & 7) == 0; }
+
 // launchers implemented in the .hip files
 int launch_colpre(const ColArgs& a, hipStream_t s);
 int launch_closed(int scheme, const SolveArgs& a, hipStream_t s, int force);
 int launch_tridiag(int scheme, const SolveArgs& a, hipStream_t s, int force);
 int init_quadrature(hipStream_t s);
 void tune_closed(int key, int value);
+void tune_tridiag(int key, int value);
+int launch_tridiag_tile(int scheme, const SolveArgs& a, hipStream_t s, bool& done);
 void host_quad_nodes(double mu_s, double* psi_nodes);
 
 }  // namespace crt

@@ -50,6 +50,8 @@ struct Sch2s {
   double h;                       // diffuse extinction              :84
   double Au, Bu, Cu, Ad, Bd, Cd;  // up/dn = A e^{-KL} + B e^{-hL} + C e^{+hL}   :125-135
   double I0, invmu;
+  double em, ep, qp, qm;          // e^{-hL_j}, e^{+hL_j} and their per-level factors (uniform dlai)
+  bool unif;
 
   __device__ inline void init(const double* rec, const BandIn& in, const SolveArgs&) {
     const double K = rec[S_KB], mu = rec[S_MU], mb = rec[S_MUBAR], cos2 = rec[S_COS2], LT = rec[S_LT];
@@ -99,12 +101,22 @@ struct Sch2s {
     Ad = in.I_dr0 * h4s;
     Bd = in.I_dr0 * h5 + in.I_df0 * h9;
     Cd = in.I_dr0 * h6 + in.I_df0 * h10;
+    unif = rec[S_UNIF] != 0.0;
+    qp = exp(h * rec[S_DL]);  // lai decreases with j: e^{-hL} grows by e^{+h dl} per level
+    qm = fast_rcp(qp);
+    em = ep = 1.0;
   }
 
-  __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) const {
+  // levels must be visited in ascending order (both kernels sweep j = 0 .. nz-1)
+  __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) {
     const double L = rec[REC_HDR + j], eK = rec[REC_HDR + nz + j];
-    const double em = exp(-h * L);
-    const double ep = 1.0 / em;
+    if (!unif || exact_level(j)) {
+      em = exp(-h * L);
+      ep = fast_rcp(em);
+    } else {
+      em *= qp;
+      ep *= qm;
+    }
     const double up = Au * eK + Bu * em + Cu * ep;
     const double dn = Ad * eK + Bd * em + Cd * ep;
     const double idr = I0 * eK;                    // :150
@@ -120,17 +132,22 @@ struct Sch2s {
 struct SchBl {
   static constexpr int NARR = 4;
   static constexpr bool SOIL = false;
-  double Kg, I_dr0, I_df0, invmu;
+  double Kg, I_dr0, I_df0, invmu, tg, qg;
+  bool unif;
 
   __device__ inline void init(const double* rec, const BandIn& in, const SolveArgs&) {
     Kg = rec[S_KB] * sqrt(1 - (in.t + in.r));  // :58-62
     I_dr0 = in.I_dr0;
     I_df0 = in.I_df0;
     invmu = rec[S_INVMU];
+    unif = rec[S_UNIF] != 0.0;
+    qg = exp(Kg * rec[S_DL]);
+    tg = 1.0;
   }
-  __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) const {
+  __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) {
     const double L = rec[REC_HDR + j], tb = rec[REC_HDR + nz + j], td = rec[REC_HDR + 2 * nz + j];
-    const double tg = exp(-Kg * L);                               // :65
+    if (!unif || exact_level(j)) tg = exp(-Kg * L);               // :65
+    else tg *= qg;
     const double idr = I_dr0 * tb;                                // :69
     const double dn = I_df0 * td + 0.5 * (I_dr0 * (tg - tb));     // :70,74,79
     o[0] = idr;
@@ -148,6 +165,9 @@ struct SchG77 {
   static constexpr int NARR = 7;
   static constexpr bool SOIL = true;
   double kb, invmu, LT, kp, kd, omr, cdf, csr, ct, gnd, I_dr0, I_df0, r, t;
+  double ed, ex, er;      // e^{-kd L}, second scattered-light exponential (see level()), e^{-kd (LT - L)}
+  double qd, qx, qr;      // their per-level factors for uniform dlai
+  bool unif;
 
   __device__ inline void init(const double* rec, const BandIn& in, const SolveArgs& a) {
     kb = rec[S_KB];
@@ -176,22 +196,37 @@ struct SchG77 {
     else
       Iscd0 = 0.5 * (in.I_dr0 * (1 - rho_c) * exp(-kp * kb * LT) - in.I_dr0 * (1 - sigma) * A0);
     gnd = in.s * (in.I_dr0 * A0 + Idf0 + Iscd0);
+    unif = rec[S_UNIF] != 0.0;
+    const double dl = rec[S_DL];
+    qd = exp(kd * dl);                       // lai decreases with j
+    qr = fast_rcp(qd);
+    qx = BF ? qr : exp(kp * kb * dl);
+    ed = ex = er = 1.0;
   }
-  __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) const {
+  // levels must be visited in ascending order
+  __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) {
     const double L = rec[REC_HDR + j], Asl = rec[REC_HDR + nz + j];
-    const double ed = exp(-kd * L);
+    if (!unif || exact_level(j)) {
+      ed = exp(-kd * L);
+      ex = BF ? exp(kd * L - (kb + kd) * LT) : exp(-kp * kb * L);
+      er = exp(-kd * (LT - L));
+    } else {
+      ed *= qd;
+      ex *= qx;
+      er *= qr;
+    }
     const double Idf = I_df0 * omr * ed;                                     // g77:73 / bf:84
     double Iscd, Iscu;
     if (BF) {
       Iscd = I_dr0 * t * ((Asl - ed) / (kd - kb));                           // bf:95
-      Iscu = I_dr0 * r * ((Asl - exp(kd * L - (kb + kd) * LT)) / (kd + kb)); // bf:99-103
+      Iscu = I_dr0 * r * ((Asl - ex) / (kd + kb));                           // bf:99-103
     } else {
       const double sigma = r + t;
-      const double Isc = I_dr0 * omr * exp(-kp * kb * L) - I_dr0 * (1 - sigma) * Asl;  // g77:84-86
+      const double Isc = I_dr0 * omr * ex - I_dr0 * (1 - sigma) * Asl;       // g77:84-86
       Iscd = 0.5 * Isc;
       Iscu = 0.5 * Isc;
     }
-    const double Isr = gnd * exp(-kd * (LT - L));                            // g77:95
+    const double Isr = gnd * er;                                             // g77:95
     const double common = cdf * Idf + csr * Iscu + ct * Iscd;
     const double ash = (1 - Asl) * common;                                   // :99-101
     const double asl = Asl * (common + kb * I_dr0);                          // :106-111
@@ -260,6 +295,9 @@ struct Sch4s {
   bool osc;           // l2 < 0
   double d[5], u[5];  // I_df_d / I_df_u = sum_k coef[k] * phi_k(x), phi = {E1, F1, phi3, phi4, e^{-kappa x}}
   double I0, invmu, LT;
+  double p1, p2, p3, p4;  // basis functions at the current level
+  double q1p, q1m, q2a, q2b;  // per-level factors for uniform dlai (q2a/q2b: e^{+-lam2 dl}, or cos/sin(lam2 dl))
+  bool unif;
 
   __device__ inline void init(const double* rec, const BandIn& in, const SolveArgs& a) {
     const double mu_s = a.mu_s;
@@ -381,18 +419,42 @@ struct Sch4s {
     }
     d[4] = tp * (mu2 * Pd0 + mu1 * Pd1);
     u[4] = tp * (mu2 * Pu0 + mu1 * Pu1);
+    unif = rec[S_UNIF] != 0.0;
+    const double dl = rec[S_DL];
+    q1p = exp(lam1 * dl);  // x = lai decreases with j
+    q1m = fast_rcp(q1p);
+    if (osc) {
+      sincos(lam2 * dl, &q2b, &q2a);  // q2a = cos, q2b = sin
+    } else {
+      q2a = exp(lam2 * dl);
+      q2b = fast_rcp(q2a);
+    }
+    p1 = p2 = p3 = p4 = 1.0;
   }
 
-  __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) const {
+  // levels must be visited in ascending order
+  __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) {
     const double x = rec[REC_HDR + j], eK = rec[REC_HDR + nz + j];
-    const double p1 = exp(-lam1 * x);
-    const double p2 = exp(-lam1 * (LT - x));
-    double p3, p4;
-    if (osc) {
-      sincos(lam2 * x, &p4, &p3);
+    if (!unif || exact_level(j)) {
+      p1 = exp(-lam1 * x);
+      p2 = exp(-lam1 * (LT - x));
+      if (osc) {
+        sincos(lam2 * x, &p4, &p3);
+      } else {
+        p3 = exp(-lam2 * x);
+        p4 = exp(-lam2 * (LT - x));
+      }
     } else {
-      p3 = exp(-lam2 * x);
-      p4 = exp(-lam2 * (LT - x));
+      p1 *= q1p;
+      p2 *= q1m;
+      if (osc) {  // rotate (cos, sin)(lam2 x) by -lam2 dl
+        const double c = p3 * q2a + p4 * q2b;
+        p4 = p4 * q2a - p3 * q2b;
+        p3 = c;
+      } else {
+        p3 *= q2a;
+        p4 *= q2b;
+      }
     }
     const double dn = d[0] * p1 + d[1] * p2 + d[2] * p3 + d[3] * p4 + d[4] * eK;
     const double up = u[0] * p1 + u[1] * p2 + u[2] * p3 + u[3] * p4 + u[4] * eK;

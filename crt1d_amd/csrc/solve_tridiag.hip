@@ -58,7 +58,7 @@ __global__ __launch_bounds__(TB) void k_n79(SolveArgs a, int rec_lds_doubles) {
     const double t = td[j];
     const double refld = (1 - t) * rho;
     const double trand = (1 - t) * tau + t;
-    const double inv = 1.0 / refld;
+    const double inv = fast_rcp(refld);
     r = trand * inv;
     s = refld - trand * trand * inv;
   };
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(TB) void k_n79(SolveArgs a, int rec_lds_doubles) {
     // row 1: first downward equation uses layer index 1 of td/tb/tbcum (:85-92), as the reference
     layer(1, r, s);
     const double d = swb * tbcum[1] * (1 - tb[1]) * (tau - rho * r);
-    const double iden = 1.0 / (1 + s * e);
+    const double iden = fast_rcp(1 + s * e);
     e = -r * iden;
     f = (d + s * f) * iden;
   }
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(TB) void k_n79(SolveArgs a, int rec_lds_doubles) {
   for (int k = 1; k < nz; ++k) {
     {  // row 2k: upward flux at level k, layer k-1 (:102-109, :122-129)
       const double d = swb * tbcum[k] * (1 - tb[k - 1]) * (rho - tau * r);
-      const double iden = 1.0 / (1 + r * e);
+      const double iden = fast_rcp(1 + r * e);
       e = -s * iden;
       f = (d + r * f) * iden;
       ef.put(k, e, f);
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(TB) void k_n79(SolveArgs a, int rec_lds_doubles) {
     if (k <= nz - 2) {  // row 2k+1: downward flux at level k, layer k (:112-119)
       layer(k, r, s);
       const double d = swb * tbcum[k + 1] * (1 - tb[k]) * (tau - rho * r);
-      const double iden = 1.0 / (1 + s * e);
+      const double iden = fast_rcp(1 + s * e);
       e = -r * iden;
       f = (d + s * f) * iden;
     }
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(TB) void k_n79(SolveArgs a, int rec_lds_doubles) {
     const double refld = (1 - t) * rho;
     const double trand = (1 - t) * tau + t;
     const double src = swb * tbcum[k + 1] * (1 - tb[k]);
-    dn = (refld * up + (trand * trand - refld * refld) * dn1 - src * (rho * refld - tau * trand)) / trand;
+    dn = (refld * up + (trand * trand - refld * refld) * dn1 - src * (rho * refld - tau * trand)) * fast_rcp(trand);
     double ee, ff;
     ef.get(k, ee, ff);
     up = ff - ee * dn;
@@ -175,13 +175,13 @@ __global__ __launch_bounds__(TB) void k_zq(SolveArgs a, int rec_lds_doubles) {
     const double dlo = 1 - qlo * q;        // 1 - r r (1-a)(1-t)(1-a)(1-t)  (:118)
     const double dhi = 1 - q * qhi;        // (:119)
     {  // row 2li-1: sub = -fwd, dia = -qlo fwd, sup = dlo (:116-118), rhs :137-139
-      const double iden = 1.0 / (-qlo * fwd + fwd * e);
+      const double iden = fast_rcp(-qlo * fwd + fwd * e);
       const double C = dlo * cu * S;
       e = dlo * iden;
       f = (C + fwd * f) * iden;
     }
     {  // row 2li: sub = dhi, dia = -qhi fwd, sup = -fwd (:119-121), rhs :140-142
-      const double iden = 1.0 / (-qhi * fwd - dhi * e);
+      const double iden = fast_rcp(-qhi * fwd - dhi * e);
       const double C = dhi * cd * S;
       e = -fwd * iden;
       f = (C - dhi * f) * iden;
@@ -205,12 +205,12 @@ __global__ __launch_bounds__(TB) void k_zq(SolveArgs a, int rec_lds_doubles) {
     const double dhi = 1 - q * qhi;
     const double dlo = 1 - qlo * q;
     // SWd0[li-1] from the original row 2li:  dhi x_{2li-1} - qhi fwd x_{2li} - fwd x_{2li+1} = C
-    const double xdl = (dhi * cd * S + qhi * fwd * xu + fwd * xd) / dhi;
+    const double xdl = (dhi * cd * S + qhi * fwd * xu + fwd * xd) * fast_rcp(dhi);
     double ee, ff;
     ef.get(z, ee, ff);
     const double xul = ff - ee * xdl;  // SWu0[li-1]
     // multiple-scattering correction, eqs. 24/25 (:180-187), at output level z = li-1
-    const double iden = 1.0 / dlo;
+    const double iden = fast_rcp(dlo);
     const double dn = (xd + q * xul) * iden;
     const double up = (xul + qlo * xd) * iden;
     const double Fss = S * invmu + 2 * xul + 2 * xd;
@@ -241,7 +241,11 @@ int set_lds_limit(K kern, size_t bytes) {
 }  // namespace
 
 int launch_tridiag(int scheme, const SolveArgs& a, hipStream_t s, int force) {
-  (void)force;
+  if (force != 1) {  // column-tile kernel (solve_tridiag_tile.hip) when it applies; force = 1 keeps the per-wave kernels
+    bool done = false;
+    const int st = launch_tridiag_tile(scheme, a, s, done);
+    if (st != CRT_OK || done) return st;
+  }
   const long long items = (long long)a.ncol * a.nb;
   const long long nblk = (items + TB - 1) / TB;
   if (nblk > 0x7fffffffLL) return CRT_ERR_UNSUPPORTED;

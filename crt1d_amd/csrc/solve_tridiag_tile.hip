@@ -1,0 +1,513 @@
+// Tridiagonal schemes (n79, zq), column-tile kernel for gfx950.
+//
+// Why a second kernel: the per-wave kernels of solve_tridiag.hip keep 16 nz bytes of Thomas state per lane in
+// LDS (2 waves per CU at nz = 60) and let every lane store its own band (512-B runs that are only 8-B aligned when
+// nb*8 is not a multiple of 128 B).  Both hurt: 0.33-0.37 of HBM peak.  Here
+//
+//  * a workgroup owns ONE whole column (all nb bands), so -- as in k_tile of solve_closed.hip -- T consecutive
+//    levels of an output array are one contiguous run that is staged in LDS and flushed with 16-B-per-lane stores
+//    covering whole 128-B lines;
+//  * the Thomas state is CHECKPOINTED: the forward sweep keeps the even-row pair (e, f) only every M-th level
+//    (nz/M pairs per lane in LDS).  The back substitution walks the segments from the top; for each segment it
+//    re-runs the forward recurrence from the segment's checkpoint into M-1 register-resident pairs and then
+//    back-substitutes through them.  Every pair is produced by exactly the arithmetic of the plain sweep, so the
+//    result is bitwise what the per-wave kernel computes -- no unstable "shooting" recurrences -- at the price
+//    of running the (cheap) forward recurrence twice.  LDS per lane drops from 16 nz to 16 nz/M bytes;
+//  * only the 4 profiles that need the solve (dn, up and the two scheme extras) go through the LDS tile; I_dr and
+//    the F arrays are linear combinations with per-band / per-level constants and are formed while flushing.
+//
+// LDS at nb = 300, nz = 60, M = 12, T = 4: checkpoints 25.6 KB + tile 38.4 KB + record/band constants 5.4 KB
+// = 69 KB -> two workgroups (10 waves) per CU.
+#include "crt_internal.hpp"
+
+namespace crt {
+namespace {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+struct TriCfg {
+  int T;        // levels per flush tile (divides M)
+  int nck;      // checkpoints per lane
+  int off_bc;   // LDS offsets in doubles: band constants
+  int off_ck;   // checkpoints [nck][2][nthr]
+  int off_tile; // tile [NST][T][nb]
+};
+
+// ------------------------------------------------------------------------------------------
+// n79 (crt1d/solvers/_solve_n79.py:70-155).  Even row k <-> upward flux at level k, k = 0 .. nz-1.
+struct TriN79 {
+  static constexpr int NST = 4;   // staged: dn, up, aI_lsl, aI_lsh
+  static constexpr int NOUT = 6;  // I_dr, I_df_d, I_df_u, F, aI_lsl, aI_lsh
+  double swb, swd, rho, tau, alb, oma, invmu;
+  double dn, up;  // back-substitution state (level k+1)
+
+  __host__ __device__ static inline int rows(int nz) { return nz; }               // even rows
+  __host__ __device__ static inline int out_rows(int arr, int nz) { return arr >= 4 ? nz - 1 : nz; }
+  __device__ inline double band_const() const { return swb; }
+
+  __device__ inline void init(const double* rec, const SolveArgs& a, int c, int b) {
+    const long long i = (long long)c * a.col_stride + b;
+    swb = a.I_dr0[i];
+    swd = a.I_df0[i];
+    rho = a.leaf_r[i];
+    tau = a.leaf_t[i];
+    alb = a.soil_r[i];
+    oma = 1 - (rho + tau);  // :56,145
+    invmu = rec[S_INVMU];
+  }
+  // layer scattering coefficients (:85-88 / :102-105): r = trand/refld, s = refld - trand^2/refld
+  __device__ inline void layer(const double* rec, int nz, int j, double& r, double& s) const {
+    const double t = rec[REC_HDR + 2 * nz + j];
+    const double refld = (1 - t) * rho;
+    const double trand = (1 - t) * tau + t;
+    const double inv = fast_rcp(refld);
+    r = trand * inv;
+    s = refld - trand * trand * inv;
+  }
+  __device__ inline void first(const double* rec, int nz, double& e, double& f) const {
+    e = -alb;  // row 0: soil, upward (:79-82)
+    f = swb * rec[REC_HDR] * alb;
+  }
+  // even pair of level k -> even pair of level k+1 (odd row of level k, then even row of level k+1)
+  __device__ inline void advance(int k, const double* rec, int nz, double& e, double& f) const {
+    const double* tbcum = rec + REC_HDR;
+    const double* tb = tbcum + nz;
+    const int mk = k == 0 ? 1 : k;  // the first downward row uses layer index 1 (:85-92), as the reference
+    double r, s;
+    layer(rec, nz, mk, r, s);
+    {
+      const double d = swb * tbcum[k + 1] * (1 - tb[mk]) * (tau - rho * r);  // (:92, :119)
+      const double iden = fast_rcp(1 + s * e);
+      e = -r * iden;
+      f = (d + s * f) * iden;
+    }
+    if (k == 0) layer(rec, nz, 0, r, s);
+    {
+      const double d = swb * tbcum[k + 1] * (1 - tb[k]) * (rho - tau * r);   // (:109, :129)
+      const double iden = fast_rcp(1 + r * e);
+      e = -s * iden;
+      f = (d + r * f) * iden;
+    }
+  }
+  // top even row (k = nz-1): dn = sky diffuse (:132-135); emits output level nz-1 (no layer above it)
+  __device__ inline void top(const double* rec, int nz, double e, double f, double (&o)[NST]) {
+    dn = swd;
+    up = f - e * dn;
+    o[0] = dn;
+    o[1] = up;
+    o[2] = 0.0;
+    o[3] = 0.0;
+  }
+  // level k from level k+1; emits output level k and layer k
+  __device__ inline void back(int k, const double* rec, int nz, double e, double f, double (&o)[NST]) {
+    const double* tbcum = rec + REC_HDR;
+    const double* tb = tbcum + nz;
+    const double t = rec[REC_HDR + 2 * nz + k];
+    const double refld = (1 - t) * rho;
+    const double trand = (1 - t) * tau + t;
+    const double src = swb * tbcum[k + 1] * (1 - tb[k]);
+    const double dn1 = dn;
+    // dn_k from the upward equation of level k+1 (layer k):  -r dn_k + up_{k+1} - s dn_{k+1} = d
+    dn = (refld * up + (trand * trand - refld * refld) * dn1 - src * (rho * refld - tau * trand)) * fast_rcp(trand);
+    up = f - e * dn;
+    const double direct = src * oma;                       // :145
+    const double diffuse = (dn1 + up) * (1 - t) * oma;     // :146
+    const double fs = rec[REC_HDR + 3 * nz + k];
+    o[0] = dn;
+    o[1] = up;
+    o[2] = (diffuse * fs + direct) * rec[REC_HDR + 4 * nz + k];  // :154
+    o[3] = (diffuse * (1 - fs)) * rec[REC_HDR + 5 * nz + k];     // :155
+  }
+  // value of output array `arr` at tile row t (level j), band b; st[] = staged arrays at that element
+  template <int ARR>
+  __device__ static inline double value(const double* rec, int nz, int j, double bc, double invmu_, const double* tile, int stride,
+                                        int idx) {
+    if constexpr (ARR == 0) return bc * rec[REC_HDR + j];                                                          // :151
+    if constexpr (ARR == 1) return tile[idx];
+    if constexpr (ARR == 2) return tile[stride + idx];
+    if constexpr (ARR == 3) return bc * rec[REC_HDR + j] * invmu_ + 2 * tile[idx] + 2 * tile[stride + idx];        // :161
+    if constexpr (ARR == 4) return tile[2 * stride + idx];
+    return tile[3 * stride + idx];
+  }
+  static constexpr bool derived(int arr) { return arr == 0 || arr == 3; }
+  static constexpr int staged_slot(int arr) { return arr == 1 ? 0 : arr == 2 ? 1 : arr == 4 ? 2 : 3; }
+  // all outputs of one (level j, band pair) from the staged pairs st[]; same expressions as value<>()
+  __device__ static inline void emit(const double* rec, int nz, int j, d2 bc, double invmu_, const d2 (&st)[NST], d2 (&o)[NOUT]) {
+    const d2 idr = bc * rec[REC_HDR + j];
+    o[0] = idr;
+    o[1] = st[0];
+    o[2] = st[1];
+    o[3] = idr * invmu_ + 2 * st[0] + 2 * st[1];
+    o[4] = st[2];
+    o[5] = st[3];
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// zq (crt1d/solvers/_solve_zq.py:74-219).  Even row k <-> SWu0[k], k = 0 .. m (m = nz); output level z = k, k < m.
+struct TriZq {
+  static constexpr int NST = 4;   // staged: I_df_d, I_df_u, I_df_d_ss, I_df_u_ss
+  static constexpr int NOUT = 7;  // I_dr, I_df_d, I_df_u, F, I_df_d_ss, I_df_u_ss, F_ss
+  double I_dr0, I_df0, rho, fwd, q, q0, cu, cd, invmu;
+  double xd, xu;  // SWd0[li], SWu0[li] of the level above
+
+  __host__ __device__ static inline int rows(int nz) { return nz + 1; }
+  __host__ __device__ static inline int out_rows(int, int nz) { return nz; }
+  __device__ inline double band_const() const { return I_dr0; }
+
+  __device__ inline void init(const double* rec, const SolveArgs& a, int c, int b) {
+    const long long i = (long long)c * a.col_stride + b;
+    I_dr0 = a.I_dr0[i];
+    I_df0 = a.I_df0[i];
+    const double bL = a.leaf_r[i], tL = a.leaf_t[i];
+    rho = a.soil_r[i];
+    const double mu = rec[S_MU], t = rec[S_TAUI], t_psi = rec[S_TPSI];
+    invmu = rec[S_INVMU];
+    const double aL = 1 - (bL + tL);                                             // :87
+    const double r_i = 2.0 / 3 * (bL / (bL + tL)) + 1.0 / 3 * (tL / (bL + tL));  // eq. 23 :40-43
+    const double r_psi = 0.5 + 0.3334 * ((bL - tL) / (bL + tL)) * mu;            // eq. 22 :35-38
+    fwd = t + (1 - t) * (1 - aL) * (1 - r_i);                                    // :116
+    q = r_i * (1 - aL) * (1 - t);
+    q0 = 1.0 * (1 - (1 - rho)) * (1 - 0.0);  // ground "layer": r=1, t=0, a=1-rho (:106-108)
+    cu = r_psi * (1 - t_psi) * (1 - aL);        // :139
+    cd = (1 - t_psi) * (1 - aL) * (1 - r_psi);  // :142
+  }
+  __device__ inline void first(const double* rec, int nz, double& e, double& f) const {
+    e = 0.0;  // row 0: x0 = rho S_0 (:115,136)
+    f = rho * (I_dr0 * rec[REC_HDR]);
+  }
+  __device__ inline void advance(int k, const double* rec, int m, double& e, double& f) const {
+    const int li = k + 1;
+    const double S = I_dr0 * rec[REC_HDR + li - 1];  // :130
+    const double qlo = (li == 1) ? q0 : q;
+    const double qhi = (li == m) ? 0.0 : q;
+    const double dlo = 1 - qlo * q;  // :118
+    const double dhi = 1 - q * qhi;  // :119
+    {  // row 2li-1: sub = -fwd, dia = -qlo fwd, sup = dlo (:116-118), rhs :137-139
+      const double iden = fast_rcp(-qlo * fwd + fwd * e);
+      const double C = dlo * cu * S;
+      e = dlo * iden;
+      f = (C + fwd * f) * iden;
+    }
+    {  // row 2li: sub = dhi, dia = -qhi fwd, sup = -fwd (:119-121), rhs :140-142
+      const double iden = fast_rcp(-qhi * fwd - dhi * e);
+      const double C = dhi * cd * S;
+      e = -fwd * iden;
+      f = (C - dhi * f) * iden;
+    }
+  }
+  // k = m: x[2m+1] = I_df0 (:122,143); no output row at k = m
+  __device__ inline void top(const double* rec, int m, double e, double f, double (&o)[NST]) {
+    xd = I_df0;
+    xu = f - e * xd;
+    o[0] = o[1] = o[2] = o[3] = 0.0;
+  }
+  __device__ inline void back(int k, const double* rec, int m, double e, double f, double (&o)[NST]) {
+    const int li = k + 1;
+    const double S = I_dr0 * rec[REC_HDR + k];
+    const double qlo = (li == 1) ? q0 : q;
+    const double qhi = (li == m) ? 0.0 : q;
+    const double dhi = 1 - q * qhi;
+    const double dlo = 1 - qlo * q;
+    // SWd0[li-1] from the original row 2li:  dhi x_{2li-1} - qhi fwd x_{2li} - fwd x_{2li+1} = C
+    const double xdl = (dhi * cd * S + qhi * fwd * xu + fwd * xd) * fast_rcp(dhi);
+    const double xul = f - e * xdl;  // SWu0[li-1]
+    const double iden = fast_rcp(dlo);   // multiple-scattering correction, eqs. 24/25 (:180-187)
+    o[0] = (xd + q * xul) * iden;
+    o[1] = (xul + qlo * xd) * iden;
+    o[2] = xd;   // I_df_d_ss :197
+    o[3] = xul;  // I_df_u_ss :199
+    xd = xdl;
+    xu = xul;
+  }
+  template <int ARR>
+  __device__ static inline double value(const double* rec, int nz, int j, double bc, double invmu_, const double* tile, int stride,
+                                        int idx) {
+    if constexpr (ARR == 0) return bc * rec[REC_HDR + j];                                                              // :219
+    if constexpr (ARR == 1) return tile[idx];
+    if constexpr (ARR == 2) return tile[stride + idx];
+    if constexpr (ARR == 3) return bc * rec[REC_HDR + j] * invmu_ + 2 * tile[stride + idx] + 2 * tile[idx];            // :202
+    if constexpr (ARR == 4) return tile[2 * stride + idx];
+    if constexpr (ARR == 5) return tile[3 * stride + idx];
+    return bc * rec[REC_HDR + j] * invmu_ + 2 * tile[3 * stride + idx] + 2 * tile[2 * stride + idx];                   // :201
+  }
+  static constexpr bool derived(int arr) { return arr == 0 || arr == 3 || arr == 6; }
+  static constexpr int staged_slot(int arr) { return arr == 1 ? 0 : arr == 2 ? 1 : arr == 4 ? 2 : 3; }
+  __device__ static inline void emit(const double* rec, int nz, int j, d2 bc, double invmu_, const d2 (&st)[NST], d2 (&o)[NOUT]) {
+    const d2 S = bc * rec[REC_HDR + j];
+    o[0] = S;
+    o[1] = st[0];
+    o[2] = st[1];
+    o[3] = S * invmu_ + 2 * st[1] + 2 * st[0];
+    o[4] = st[2];
+    o[5] = st[3];
+    o[6] = S * invmu_ + 2 * st[3] + 2 * st[2];
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// flush one output array: rows [j0, j0 + nrows) of column c, one contiguous run
+template <class S, int ARR>
+__device__ inline void flush_array(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride,
+                                   int c, int j0, int nrows, double invmu, float inv_nb) {
+  if (nrows <= 0) return;
+  const int nb = a.nb, nz = a.nz;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int n = nrows * nb;
+  double* g = a.o[ARR] + ((long long)c * S::out_rows(ARR, nz) + j0) * nb;
+  const int mis = (int)((reinterpret_cast<uintptr_t>(g) >> 3) & 1);
+  const int npair = (n - mis) >> 1;
+  auto elem = [&](int i) -> double {
+    if constexpr (S::derived(ARR)) {
+      int t = (int)(((float)i + 0.5f) * inv_nb);
+      int b = i - t * nb;
+      if (b < 0) { --t; b += nb; }
+      if (b >= nb) { ++t; b -= nb; }
+      return S::template value<ARR>(rec, nz, j0 + t, bandc[b], invmu, tile, tstride, i);
+    } else {
+      return tile[S::staged_slot(ARR) * tstride + i];
+    }
+  };
+  d2* g2 = reinterpret_cast<d2*>(g + mis);
+  for (int i = tid; i < npair; i += nthr) {
+    d2 v;
+    v.x = elem(mis + 2 * i);
+    v.y = elem(mis + 2 * i + 1);
+    g2[i] = v;
+  }
+  if (tid == 0) {
+    if (mis) g[0] = elem(0);
+    if ((n - mis) & 1) g[n - 1] = elem(n - 1);
+  }
+}
+
+template <class S, int ARR>
+__device__ inline void flush_arrays(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride, int c,
+                                    int j0, int T, double invmu, float inv_nb) {
+  const int nr = min(j0 + T, S::out_rows(ARR, a.nz)) - j0;
+  flush_array<S, ARR>(a, rec, bandc, tile, tstride, c, j0, nr, invmu, inv_nb);
+  if constexpr (ARR + 1 < S::NOUT) flush_arrays<S, ARR + 1>(a, rec, bandc, tile, tstride, c, j0, T, invmu, inv_nb);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused flush for even nb (a band pair never straddles a row and every row is 16-B aligned): thread -> (row offset,
+// band pair) is fixed for the whole kernel, so there is no index arithmetic per element; the 4 staged pairs are read
+// once and all NOUT arrays are stored in the same pass.  Rows of a tile are adjacent in memory, so consecutive threads
+// still write consecutive 16-B words: every wave store is a contiguous, line-aligned 1 KiB.
+struct FlushMap {
+  int t_off;  // row of the tile this thread starts at
+  int p;      // band pair
+  int rpi;    // rows covered per iteration by the workgroup
+  bool on;
+};
+
+template <class S, int T>
+__device__ inline void flush_fused(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int c, int j0,
+                                   const FlushMap& fm, double invmu) {
+  const int nb2 = a.nb >> 1, nz = a.nz;
+  const d2* tile2 = reinterpret_cast<const d2*>(tile);
+  const d2 bc = reinterpret_cast<const d2*>(bandc)[fm.p];
+  for (int t = fm.t_off; t < T; t += fm.rpi) {
+    const int j = j0 + t;
+    if (!fm.on || j >= nz) continue;
+    d2 st[S::NST], o[S::NOUT];
+#pragma unroll
+    for (int q = 0; q < S::NST; ++q) st[q] = tile2[(q * T + t) * nb2 + fm.p];
+    S::emit(rec, nz, j, bc, invmu, st, o);
+#pragma unroll
+    for (int k = 0; k < S::NOUT; ++k) {
+      const int rows = S::out_rows(k, nz);
+      if (j < rows) reinterpret_cast<d2*>(a.o[k])[((long long)c * rows + j) * nb2 + fm.p] = o[k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The segment loops are fully unrolled: the register-resident pairs be[M], bf[M] need static indices (a runtime-indexed
+// array goes to scratch; VGPR-index mode on vector types works but costs ~40 instructions per level, measured).
+template <class S, int M, int T, int MAXT, bool FUSED>
+__global__ __launch_bounds__(MAXT) void k_tri_tile(SolveArgs a, TriCfg cfg) {
+  static_assert(M % T == 0, "tile height must divide the checkpoint spacing");
+  extern __shared__ double lds[];
+  const int nb = a.nb, nz = a.nz;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int c = blockIdx.x;
+  {
+    const double* src = a.ws + (long long)c * a.reclen;
+    for (int i = tid; i < a.reclen; i += nthr) lds[i] = src[i];
+  }
+  __syncthreads();
+  const double* rec = lds;
+  double* bandc = lds + cfg.off_bc;
+  double* ck = lds + cfg.off_ck + tid;       // [nck][2][nthr]
+  double* tile = lds + cfg.off_tile;         // [NST][T][nb]
+  const int tstride = T * nb;
+  const bool active = tid < nb;
+  const int b = active ? tid : 0;
+  const float inv_nb = 1.0f / (float)nb;
+  const double invmu = rec[S_INVMU];
+  FlushMap fm;
+  {
+    const int nb2 = nb >> 1;
+    fm.rpi = nthr / nb2;  // >= 2 because nthr >= nb
+    fm.t_off = tid / nb2;
+    fm.p = tid - fm.t_off * nb2;
+    fm.on = fm.t_off < fm.rpi;
+  }
+
+  S st;
+  st.init(rec, a, c, b);
+  if (active) bandc[b] = st.band_const();
+  const int K = S::rows(nz);
+
+  // ---- pass 1: forward recurrence, keep the even-row pair of every M-th level ----
+  double e, f;
+  st.first(rec, nz, e, f);
+  ck[0] = e;
+  ck[nthr] = f;
+  for (int k = 0; k + 1 < K; ++k) {
+    st.advance(k, rec, nz, e, f);
+    if ((k + 1) % M == 0) {
+      const int s = (k + 1) / M;
+      ck[(2 * s) * nthr] = e;
+      ck[(2 * s + 1) * nthr] = f;
+    }
+  }
+
+  // ---- pass 2: segments from the top; recompute the segment's pairs into registers, back-substitute, flush ----
+  for (int seg = (K - 1) / M; seg >= 0; --seg) {
+    const int k0 = seg * M;
+    const int kend = min(k0 + M - 1, K - 1);
+    double be[M], bf[M];  // pairs of levels k0 .. k0+M-1 (statically indexed: the loops below are fully unrolled)
+    be[0] = ck[(2 * seg) * nthr];
+    bf[0] = ck[(2 * seg + 1) * nthr];
+#pragma unroll
+    for (int i = 1; i < M; ++i) {
+      be[i] = be[i - 1];
+      bf[i] = bf[i - 1];
+      if (k0 + i <= kend) st.advance(k0 + i - 1, rec, nz, be[i], bf[i]);
+    }
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+      const int k = k0 + i;
+      if (k <= kend) {
+        double o[S::NST];
+        if (k == K - 1)
+          st.top(rec, nz, be[i], bf[i], o);
+        else
+          st.back(k, rec, nz, be[i], bf[i], o);
+        if (active) {
+#pragma unroll
+          for (int q = 0; q < S::NST; ++q) tile[q * tstride + (i % T) * nb + b] = o[q];
+        }
+      }
+      if (i % T == 0) {  // bottom row of a tile (T divides M, segments start at multiples of M)
+        if (k <= kend) {
+          __syncthreads();
+          if constexpr (FUSED)
+            flush_fused<S, T>(a, rec, bandc, tile, c, k, fm, invmu);
+          else
+            flush_arrays<S, 0>(a, rec, bandc, tile, tstride, c, k, T, invmu, inv_nb);
+          __syncthreads();
+        }
+      }
+    }
+  }
+}
+
+constexpr size_t MAX_WG_LDS = 160 * 1024;
+
+template <class S, int M, int T, bool FUSED>
+int launch_mt(const SolveArgs& a, hipStream_t s, int nthr) {
+  const int K = S::rows(a.nz);
+  TriCfg cfg;
+  cfg.T = T;
+  cfg.nck = (K - 1) / M + 1;
+  cfg.off_bc = (a.reclen + 1) & ~1;
+  cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
+  cfg.off_tile = cfg.off_ck + 2 * cfg.nck * nthr;
+  const size_t sh = ((size_t)cfg.off_tile + (size_t)S::NST * T * a.nb) * sizeof(double);
+  if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
+  const void* fn = nthr <= 256 ? (const void*)k_tri_tile<S, M, T, 256, FUSED> : nthr <= 512 ? (const void*)k_tri_tile<S, M, T, 512, FUSED>
+                                                                                      : (const void*)k_tri_tile<S, M, T, 1024, FUSED>;
+  if (sh > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+    return CRT_ERR_LAUNCH;
+  dim3 grid(a.ncol), block(nthr);
+  if (nthr <= 256)
+    hipLaunchKernelGGL((k_tri_tile<S, M, T, 256, FUSED>), grid, block, sh, s, a, cfg);
+  else if (nthr <= 512)
+    hipLaunchKernelGGL((k_tri_tile<S, M, T, 512, FUSED>), grid, block, sh, s, a, cfg);
+  else
+    hipLaunchKernelGGL((k_tri_tile<S, M, T, 1024, FUSED>), grid, block, sh, s, a, cfg);
+  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+}
+
+int g_tri_tune[4] = {0, 0, 0, 0};  // [0] force M (8/12/16), [1] force T (4/8)
+
+// instantiated (M, T) pairs
+template <class S, bool FUSED>
+int launch_cfg(const SolveArgs& a, hipStream_t s, int M, int T, int nthr) {
+  if (M == 8 && T == 4) return launch_mt<S, 8, 4, FUSED>(a, s, nthr);
+  if (M == 8 && T == 8) return launch_mt<S, 8, 8, FUSED>(a, s, nthr);
+  if (M == 12 && T == 4) return launch_mt<S, 12, 4, FUSED>(a, s, nthr);
+  if (M == 12 && T == 12) return launch_mt<S, 12, 12, FUSED>(a, s, nthr);
+  if (M == 16 && T == 4) return launch_mt<S, 16, 4, FUSED>(a, s, nthr);
+  if (M == 16 && T == 8) return launch_mt<S, 16, 8, FUSED>(a, s, nthr);
+  return CRT_ERR_UNSUPPORTED;
+}
+
+template <class S>
+int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done) {
+  done = false;
+  if (a.nb < 64 || a.nb > 1024) return CRT_OK;
+  const int nthr = ((a.nb + 63) / 64) * 64;
+  const int K = S::rows(a.nz);
+  auto lds_bytes = [&](int M, int T) {
+    const int nck = (K - 1) / M + 1;
+    return ((size_t)a.reclen + a.nb + 4 + 2 * (size_t)nck * nthr + (size_t)S::NST * T * a.nb) * sizeof(double);
+  };
+  // Measured on MI355X at 1e4 x 300 (tools/ab_tri.py, interleaved rounds, fused flush):
+  //   n79 nz=60 : M12/T4 (2 WG/CU) 1.84 ms | M8/T8 2.25 | M16/T4 2.37 | M8/T4 2.28 | per-wave kernel 2.79
+  //   zq  nz=60 : M8/T8 (1 WG/CU) 1.91 ms | M16/T8 1.92 | M12/T4 2.02 | per-wave 2.47
+  //   zq  nz=100: M8/T8 3.11 ms | M16/T8 3.16 | M8/T4 3.18 | M12/T4 3.20 | per-wave 5.15
+  int M = 0, T = 0;
+  const int pref_n79[6][2] = {{12, 4}, {8, 8}, {16, 8}, {8, 4}, {16, 4}, {12, 12}};
+  const int pref_zq[6][2] = {{8, 8}, {16, 8}, {12, 4}, {8, 4}, {16, 4}, {12, 12}};
+  const int (*pref)[2] = S::NOUT == 6 ? pref_n79 : pref_zq;
+  for (int i = 0; i < 6 && !M; ++i) {
+    const size_t need = lds_bytes(pref[i][0], pref[i][1]);
+    // a (M, 4) choice is only worth it when it leaves two workgroups per CU
+    const size_t budget = pref[i][1] == 4 && i == 0 ? 78 * 1024 : MAX_WG_LDS;
+    if (need <= budget) { M = pref[i][0]; T = pref[i][1]; }
+  }
+  if (g_tri_tune[0] > 0) {
+    M = g_tri_tune[0];
+    T = g_tri_tune[1] > 0 ? g_tri_tune[1] : 4;
+    if (lds_bytes(M, T) > MAX_WG_LDS) return CRT_OK;
+  }
+  if (!M) return CRT_OK;
+  // fused flush needs even nb and 16-B aligned output arrays
+  bool fused = (a.nb % 2 == 0);
+  for (int i = 0; i < S::NOUT && fused; ++i)
+    if (reinterpret_cast<uintptr_t>(a.o[i]) & 15) fused = false;
+  const int st = fused ? launch_cfg<S, true>(a, s, M, T, nthr) : launch_cfg<S, false>(a, s, M, T, nthr);
+  if (st == CRT_ERR_UNSUPPORTED) return CRT_OK;
+  done = st == CRT_OK;
+  return st;
+}
+
+}  // namespace
+
+void tune_tridiag(int key, int value) {
+  if (key >= 0 && key < 4) g_tri_tune[key] = value;
+}
+
+// returns CRT_OK with done = false when the column-tile kernel does not apply (caller falls back)
+int launch_tridiag_tile(int scheme, const SolveArgs& a, hipStream_t s, bool& done) {
+  if (scheme == CRT_SCHEME_N79) return launch_scheme<TriN79>(a, s, done);
+  if (scheme == CRT_SCHEME_ZQ) return launch_scheme<TriZq>(a, s, done);
+  done = false;
+  return CRT_ERR_BAD_ARG;
+}
+
+}  // namespace crt

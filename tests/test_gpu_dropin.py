@@ -139,8 +139,9 @@ def test_epilogue_kernels_vs_oracle(oracle):
     np.testing.assert_allclose(tot[:, 2, 0] - tot[:, 2, 1] - (tot[:, 2, 2] - tot[:, 2, 3]), canopy, rtol=1e-10)
 
 
-@pytest.mark.parametrize("scheme", ["2s", "4s", "bl", "g77", "bf"])
-@pytest.mark.parametrize("shape", [(33, 300, 60), (5, 107, 61), (9, 64, 13), (7, 100, 60), (3, 128, 7), (2, 512, 33), (2, 1024, 9), (130, 77, 5)])
+@pytest.mark.parametrize("scheme", ["2s", "4s", "bl", "g77", "bf", "n79", "zq"])
+@pytest.mark.parametrize("shape", [(33, 300, 60), (5, 107, 61), (9, 64, 13), (7, 100, 60), (3, 128, 7), (2, 512, 33), (2, 1024, 9), (130, 77, 5),
+                                   (4, 300, 100), (3, 65, 3), (2, 300, 8), (2, 96, 12), (2, 200, 25)])
 def test_tile_kernel_equals_direct_kernel(scheme, shape):
     """The LDS-tiled, line-aligned kernel and the direct-store kernel run the same per-lane arithmetic:
     results must be BITWISE equal for every shape class (odd nb, several columns per workgroup, ragged last tile...)."""
