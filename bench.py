@@ -35,12 +35,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 N_IO = {  # scheme: (n_in, n_full, n_mid)
     "2s": (5, 4, 0), "4s": (5, 4, 0), "bl": (4, 4, 0), "g77": (5, 7, 0), "bf": (5, 7, 0), "n79": (5, 4, 2), "zq": (5, 7, 0),
 }
-KERNEL_NAMES = {"2s": "k_2s", "4s": "k_4s", "bl": "k_bl", "g77": "k_g77", "bf": "k_g77", "n79": "k_n79", "zq": "k_zq"}
+# dominant kernel per scheme as rocprofv3 names it (template arguments abbreviated)
+KERNEL_NAMES = {"2s": "k_tile<Sch2s>", "4s": "k_tile<Sch4s>", "bl": "k_tile<SchBl>", "g77": "k_tile<SchG77<false>>",
+                "bf": "k_tile<SchG77<true>>", "n79": "k_tri_tile<TriN79>", "zq": "k_tri_tile<TriZq>"}
 
 
-def bytes_per_solve(scheme, nz):
+def bytes_per_solve(scheme, nz, s=8):
     n_in, n_full, n_mid = N_IO[scheme]
-    return 8 * (n_in + n_full * nz + n_mid * (nz - 1))
+    return s * (n_in + n_full * nz + n_mid * (nz - 1))
 
 
 def cpu_baseline(scheme, nb, nz, budget_s=15.0):
@@ -86,14 +88,17 @@ def cpu_baseline(scheme, nb, nz, budget_s=15.0):
     }
 
 
-def load_pmc_traffic(scheme):
-    """HBM bytes per launch of the solve kernel from the committed rocprofv3 --pmc summary, if any."""
+def load_pmc_traffic(scheme, ncol, nb, nz):
+    """HBM bytes per launch of the solve kernel from the committed rocprofv3 --pmc summary (separate WRITE_SIZE /
+    FETCH_SIZE passes of this same command, profiles/), if one exists for exactly this configuration."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
             d = json.load(f)
         e = d.get(scheme)
-        return None if e is None else e.get("hbm_bytes_per_launch")
+        if e is None or e.get("shape") != [ncol, nb, nz]:
+            return None
+        return e.get("hbm_bytes_per_launch")
     except Exception:
         return None
 
@@ -107,7 +112,12 @@ def main():
     ap.add_argument("--ncol", type=int, default=10000, help="columns PER GPU")
     ap.add_argument("--nb", type=int, default=300)
     ap.add_argument("--nz", type=int, default=60)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
+                    help="storage type of spectra/profiles; arithmetic is fp64 either way (f32 = config 5 variant, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; 'gloo' + --share-device rehearses the N>1 code path on a one-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     a = ap.parse_args()
 
@@ -121,10 +131,16 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit(f"--gpus {a.gpus} needs: python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...")
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
+    red_dev = dev if a.backend == "nccl" else torch.device("cpu")
 
     from crt1d_amd import _lib, batched, synth
 
@@ -132,6 +148,10 @@ def main():
     # column shard of this rank: its own seed -> distinct columns of one global grid
     d = synth.make_columns(ncol, nb, nz, seed=1234 + rank)
     cols = batched.Columns.from_host(d, dev)
+    if a.dtype == "f32":
+        import numpy as np
+
+        d = {k: (v.astype(np.float32) if k in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r") else v) for k, v in d.items()}
     bands = batched.Bands.from_host(d, dev)
     plan = batched.Plan(scheme, cols, bands)
     stream = torch.cuda.current_stream(dev)
@@ -151,7 +171,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     solves_per_step = ncol * nb * world
@@ -180,7 +200,7 @@ def main():
     torch.cuda.synchronize(dev)
     k0_ms = e0.elapsed_time(e1) / 10
 
-    bps = bytes_per_solve(scheme, nz)
+    bps = bytes_per_solve(scheme, nz, 4 if a.dtype == "f32" else 8)
     alg_bytes = bps * ncol * nb  # per launch, this GPU
     achieved = alg_bytes / (k_ms_avg * 1e-3) / 1e9
 
@@ -218,7 +238,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": "f64" if a.dtype == "f64" else "f64 arithmetic, f32 storage",
         "data": "synthetic",
         "config": {
             "workload": f"solve_{scheme} batched: {ncol} synthetic profiles x {nb} bands x {nz} levels per GPU, fp64 "
@@ -234,7 +254,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": load_pmc_traffic(scheme),
+            "traffic": load_pmc_traffic(scheme, ncol, nb, nz) if a.dtype == "f64" else None,
             "algorithmic_bytes_per_launch": alg_bytes,
             "bytes_per_solve": bps,
             "kernel_ms_avg": k_ms_avg,

@@ -77,6 +77,14 @@ EXPORTS = [
     "crt_hip_bl_f64",
     "crt_hip_g77_f64",
     "crt_hip_bf_f64",
+    "crt_hip_solve_f32",
+    "crt_hip_2s_f32",
+    "crt_hip_4s_f32",
+    "crt_hip_n79_f32",
+    "crt_hip_zq_f32",
+    "crt_hip_bl_f32",
+    "crt_hip_g77_f32",
+    "crt_hip_bf_f32",
     "crt_hip_absorb_bandsum_f64",
     "crt_hip_absorb_f64",
     "crt_hip_tune",
@@ -124,10 +132,13 @@ def load():
     ]
     lib.crt_hip_solve_f64.restype = ctypes.c_int
     lib.crt_hip_solve_f64.argtypes = [ctypes.c_int] + solve_args
+    lib.crt_hip_solve_f32.restype = ctypes.c_int
+    lib.crt_hip_solve_f32.argtypes = [ctypes.c_int] + solve_args
     for s in SCHEME_IDS:
-        f = getattr(lib, f"crt_hip_{s}_f64")
-        f.restype = ctypes.c_int
-        f.argtypes = solve_args
+        for suffix in ("f64", "f32"):  # the f32 structs share the f64 layout (include/crt1d_hip.h)
+            f = getattr(lib, f"crt_hip_{s}_{suffix}")
+            f.restype = ctypes.c_int
+            f.argtypes = solve_args
     lib.crt_hip_absorb_bandsum_f64.restype = ctypes.c_int
     lib.crt_hip_absorb_bandsum_f64.argtypes = [
         ctypes.POINTER(CrtColumns), ctypes.POINTER(CrtBands), _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp,

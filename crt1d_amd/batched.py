@@ -43,6 +43,17 @@ def _f64(t, name):
     return t.contiguous()
 
 
+def _fio(t, name):
+    """Spectra may be float64 (crt_hip_*_f64) or float32 (crt_hip_*_f32: half the HBM bytes, fp64 arithmetic)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.dtype not in (torch.float64, torch.float32):
+        raise TypeError(f"{name} must be float64 or float32, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (got {t.device}); crt1d_amd has no CPU path")
+    return t.contiguous()
+
+
 @dataclass
 class Columns:
     """Device-resident per-column canopy geometry (what one reference ``Model`` holds)."""
@@ -119,11 +130,16 @@ class Bands:
 
     def __post_init__(self):
         shape = None
+        self.dtype = None
         for name in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r"):
             v = getattr(self, name)
             if v is None:
                 continue
-            v = _f64(v, name)
+            v = _fio(v, name)
+            if self.dtype is None:
+                self.dtype = v.dtype
+            elif v.dtype != self.dtype:
+                raise TypeError("all band arrays must share one dtype")
             if v.ndim == 1:
                 v = v[None, :]
             if v.ndim != 2:
@@ -172,11 +188,11 @@ def workspace_bytes(scheme, ncol, nz):
     return int(_lib.load().crt_hip_workspace_bytes(_lib.SCHEME_IDS[scheme], ncol, nz))
 
 
-def alloc_outputs(scheme, ncol, nz, nb, device):
+def alloc_outputs(scheme, ncol, nz, nb, device, dtype=torch.float64):
     out = {}
     for k in OUT_KEYS[scheme]:
         n = nz - 1 if k in _MID_KEYS.get(scheme, ()) else nz
-        out[k] = torch.empty((ncol, n, nb), dtype=torch.float64, device=device)
+        out[k] = torch.empty((ncol, n, nb), dtype=dtype, device=device)
     return out
 
 
@@ -197,7 +213,11 @@ class Plan:
             raise ValueError("solve_2s needs `mla`")
         if scheme != "bl" and bands.soil_r is None:
             raise ValueError(f"solve_{scheme} needs `soil_r`")
-        self.out = alloc_outputs(scheme, ncol, nz, nb, cols.device) if out is None else out
+        self.out = alloc_outputs(scheme, ncol, nz, nb, cols.device, bands.dtype) if out is None else out
+        for k in OUT_KEYS[scheme]:
+            v = self.out[k]
+            if v.dtype != bands.dtype or not v.is_cuda or not v.is_contiguous():
+                raise TypeError(f"output {k!r} must be a contiguous CUDA tensor of dtype {bands.dtype}")
         need = workspace_bytes(scheme, ncol, nz)
         if workspace is None:
             workspace = torch.empty(need, dtype=torch.uint8, device=cols.device)
@@ -210,7 +230,8 @@ class Plan:
         ptrs = [self.out[k].data_ptr() for k in OUT_KEYS[scheme]]
         ptrs += [None] * (7 - len(ptrs))
         self._out = _lib.CrtOutputs(*ptrs)
-        self._fn = getattr(self.lib, f"crt_hip_{scheme}_f64")
+        self._entry = f"crt_hip_{scheme}_{'f32' if bands.dtype == torch.float32 else 'f64'}"
+        self._fn = getattr(self.lib, self._entry)
         self._wsb = workspace.numel() * workspace.element_size()
 
     def __call__(self, stream=None, *, flags=0):
@@ -221,7 +242,7 @@ class Plan:
         self._o.flags = int(flags)
         st = self._fn(ctypes.byref(self._c), ctypes.byref(self._b), ctypes.byref(self._o), ctypes.byref(self._out),
                       self.workspace.data_ptr(), self._wsb, s.cuda_stream)
-        _lib.check(st, f"crt_hip_{self.scheme}_f64")
+        _lib.check(st, self._entry)
         return self.out
 
 

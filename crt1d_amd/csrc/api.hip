@@ -229,8 +229,8 @@ int crt_hip_quad_nodes(double mu_s, double* psi_nodes) {
   return CRT_OK;
 }
 
-int crt_hip_solve_f64(int scheme, const crt_columns* cols, const crt_bands* bands, const crt_options* opts,
-                      const crt_outputs* out, void* workspace, size_t workspace_bytes, crt_stream_t stream) {
+static int solve_impl(int scheme, const crt_columns* cols, const crt_bands* bands, const crt_options* opts,
+                      const crt_outputs* out, void* workspace, size_t workspace_bytes, crt_stream_t stream, int f32) {
   if (!scheme_ok(scheme) || !cols || !bands || !out) return CRT_ERR_BAD_ARG;
   const int ncol = cols->ncol, nz = cols->nz, nb = bands->nb;
   if (ncol <= 0 || nz <= 0 || nb <= 0) return CRT_ERR_BAD_ARG;
@@ -300,8 +300,23 @@ int crt_hip_solve_f64(int scheme, const crt_columns* cols, const crt_bands* band
   sa.o[5] = out->x1;
   sa.o[6] = out->x2;
   sa.mu_s = mu_s;
+  sa.f32 = f32;
   const int force = (flags & CRT_FLAG_DIRECT_STORES) ? 1 : 0;
   return tri ? launch_tridiag(scheme, sa, s, force) : launch_closed(scheme, sa, s, force);
+}
+
+
+int crt_hip_solve_f64(int scheme, const crt_columns* cols, const crt_bands* bands, const crt_options* opts,
+                      const crt_outputs* out, void* workspace, size_t workspace_bytes, crt_stream_t stream) {
+  return solve_impl(scheme, cols, bands, opts, out, workspace, workspace_bytes, stream, 0);
+}
+
+// the f32 structs have the layout of the f64 ones (pointers + sizes); only the element type behind the pointers differs
+int crt_hip_solve_f32(int scheme, const crt_columns* cols, const crt_bands_f32* bands, const crt_options* opts,
+                      const crt_outputs_f32* out, void* workspace, size_t workspace_bytes, crt_stream_t stream) {
+  static_assert(sizeof(crt_bands_f32) == sizeof(crt_bands) && sizeof(crt_outputs_f32) == sizeof(crt_outputs), "layout");
+  return solve_impl(scheme, cols, reinterpret_cast<const crt_bands*>(bands), opts, reinterpret_cast<const crt_outputs*>(out), workspace,
+                    workspace_bytes, stream, 1);
 }
 
 #define CRT_ENTRY(name, id)                                                                                        \
@@ -317,6 +332,20 @@ CRT_ENTRY(crt_hip_bl_f64, CRT_SCHEME_BL)
 CRT_ENTRY(crt_hip_g77_f64, CRT_SCHEME_G77)
 CRT_ENTRY(crt_hip_bf_f64, CRT_SCHEME_BF)
 #undef CRT_ENTRY
+
+#define CRT_ENTRY32(name, id)                                                                                      \
+  int name(const crt_columns* c, const crt_bands_f32* b, const crt_options* o, const crt_outputs_f32* out, void* ws, \
+           size_t wsb, crt_stream_t s) {                                                                           \
+    return crt_hip_solve_f32(id, c, b, o, out, ws, wsb, s);                                                        \
+  }
+CRT_ENTRY32(crt_hip_2s_f32, CRT_SCHEME_2S)
+CRT_ENTRY32(crt_hip_4s_f32, CRT_SCHEME_4S)
+CRT_ENTRY32(crt_hip_n79_f32, CRT_SCHEME_N79)
+CRT_ENTRY32(crt_hip_zq_f32, CRT_SCHEME_ZQ)
+CRT_ENTRY32(crt_hip_bl_f32, CRT_SCHEME_BL)
+CRT_ENTRY32(crt_hip_g77_f32, CRT_SCHEME_G77)
+CRT_ENTRY32(crt_hip_bf_f32, CRT_SCHEME_BF)
+#undef CRT_ENTRY32
 
 int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, const double* I_dr, const double* I_df_d,
                                const double* I_df_u, const double* band_w, int32_t ngroup, double* aI, double* aI_sl,
@@ -395,7 +424,7 @@ int crt_hip_probe_fill_f64(double* dst, size_t n, double value, crt_stream_t str
 int crt_hip_probe_copy_f64(double* dst, const double* src, size_t n, crt_stream_t stream) {
   if (!dst || !src || n == 0 || (n & 1) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15))
     return CRT_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_copy, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<d2*>(dst),
+  hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<d2*>(dst),
                      reinterpret_cast<const d2*>(src), n / 2);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }

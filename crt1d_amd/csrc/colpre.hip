@@ -126,15 +126,21 @@ __device__ inline double tau_d_9sky(const double* k9, double L) {
   return s * (2.0 * 0.17453292519943295);  // * 2 radians(10), common.py:51
 }
 
+__device__ inline double wave_sum64(double v) {  // fixed tree order -> bitwise reproducible
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return __shfl(v, 0, 64);
+}
+
 __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   __shared__ double kq[NQT];    // K_b(psi_q) = G/cos at the tau_d nodes
-  __shared__ double pmb[NQT];   // mu_bar partial sums
-  __shared__ double pg[NQG];    // G-integral partial sums
+  __shared__ double pmb[NQT];   // mu_bar terms, later tau_d(dlai_mean) terms
+  __shared__ double pg[NQG];    // G-integral terms
   __shared__ double k9[CRT_NQ_9SKY];
-  __shared__ double sh_kb;
+  __shared__ double sh_kb, sh_dlm;
 
   const int c = blockIdx.x;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nz = a.nz;
   const int kind = a.g_kind[c];
   const double param = a.g_param ? a.g_param[c] : 0.0;
@@ -162,64 +168,72 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   }
   __syncthreads();
 
-  if (tid == 0) {
+  // ---- header: wave 0, reductions by shuffles ----
+  if (wave == 0) {
     const double psi = a.psi[c];
     const double cs = cos(psi), sn = sin(psi);
     const double G = tab ? a.g_at_psi[c] : G_closed(kind, param, cs, sn);
     const double Kb = G / cs;
-    double hdr[REC_HDR];
-    for (int i = 0; i < REC_HDR; ++i) hdr[i] = 0.0;
-    hdr[S_KB] = Kb;
-    hdr[S_MU] = cs;
-    hdr[S_G] = G;
-    hdr[S_INVMU] = 1.0 / cs;
-    hdr[S_LT] = lai[0];
-    {
-      // uniform-dlai detection (lets the solve kernels advance exponentials by recurrence)
-      const double dl = (lai[0] - lai[nz - 1]) / (nz - 1);
-      const double tol = 4.0 * 2.220446049250313e-16 * fabs(lai[0]);
-      bool unif = dl > 0.0;
-      for (int j = 0; j + 1 < nz; ++j) unif = unif && fabs((lai[j] - lai[j + 1]) - dl) <= tol;
-      hdr[S_UNIF] = unif ? 1.0 : 0.0;
-      hdr[S_DL] = dl;
+    // uniform-dlai detection (lets the solve kernels advance exponentials by recurrence)
+    const double dl = (lai[0] - lai[nz - 1]) / (nz - 1);
+    const double tol = 4.0 * 2.220446049250313e-16 * fabs(lai[0]);
+    bool ok = dl > 0.0;
+    double dsum = 0.0;  // zq: sum and count of the non-zero diff(lai)   _solve_zq.py:30,50
+    double dcnt = 0.0;
+    for (int j = lane; j + 1 < nz; j += 64) {
+      const double d = lai[j] - lai[j + 1];
+      ok = ok && fabs(d - dl) <= tol;
+      if (d != 0.0) {
+        dsum -= d;  // diff(lai) = lai[j+1] - lai[j]
+        dcnt += 1.0;
+      }
     }
-    if (a.scheme == CRT_SCHEME_2S) {
-      double s = 0.0;
-      for (int q = 0; q < NQT; ++q) s += pmb[q];  // fixed order: bitwise reproducible
-      hdr[S_MUBAR] = s;
-      const double cm = cos(a.mla[c] * (M_PI / 180.0));
-      hdr[S_COS2] = cm * cm;
-    }
+    const bool unif = __all(ok);
+    double mubar = 0.0, g1 = 0.0, g2 = 0.0, dlm = 0.0;
+    if (a.scheme == CRT_SCHEME_2S) mubar = wave_sum64(pmb[lane] + (lane < NQT - 64 ? pmb[64 + lane] : 0.0));
     if (a.scheme == CRT_SCHEME_4S) {
-      double s0 = 0.0, s1 = 0.0;
-      for (int i = 0; i < NGL; ++i) {
-        s0 += pg[i];
-        s1 += pg[NGL + i];
-      }
-      hdr[S_GINT1] = s0;
-      hdr[S_GINT2] = s1;
+      g1 = wave_sum64(lane < NGL ? pg[lane] : 0.0);
+      g2 = wave_sum64(lane < NGL ? pg[NGL + lane] : 0.0);
     }
-    if (a.scheme == CRT_SCHEME_ZQ) {
-      // dlai_mean = |mean(diff(lai)[diff(lai) != 0])|   _solve_zq.py:30,50
-      double s = 0.0;
-      int n = 0;
-      for (int j = 0; j + 1 < nz; ++j) {
-        const double d = lai[j + 1] - lai[j];
-        if (d != 0.0) {
-          s += d;
-          ++n;
-        }
+    if (a.scheme == CRT_SCHEME_ZQ) dlm = fabs(wave_sum64(dsum) / wave_sum64(dcnt));
+    if (lane == 0) {
+      rec[S_KB] = Kb;
+      rec[S_MU] = cs;
+      rec[S_G] = G;
+      rec[S_MUBAR] = mubar;
+      rec[S_GINT1] = g1;
+      rec[S_GINT2] = g2;
+      rec[S_DLM] = dlm;
+      rec[S_TAUI] = 0.0;
+      rec[S_TPSI] = a.scheme == CRT_SCHEME_ZQ ? exp(-Kb * dlm) : 0.0;  // _solve_zq.py:52
+      double cos2 = 0.0;
+      if (a.scheme == CRT_SCHEME_2S) {
+        const double cm = cos(a.mla[c] * (M_PI / 180.0));
+        cos2 = cm * cm;
       }
-      const double dlm = fabs(s / n);
-      hdr[S_DLM] = dlm;
-      hdr[S_TAUI] = tau_d_quad(kq, dlm);  // _solve_zq.py:51 (always 'quad')
-      hdr[S_TPSI] = exp(-Kb * dlm);       // :52
+      rec[S_COS2] = cos2;
+      rec[S_LT] = lai[0];
+      rec[S_INVMU] = 1.0 / cs;
+      rec[S_UNIF] = unif ? 1.0 : 0.0;
+      rec[S_DL] = dl;
+      rec[14] = 0.0;
+      rec[15] = 0.0;
+      sh_kb = Kb;
+      sh_dlm = dlm;
     }
-    for (int i = 0; i < REC_HDR; ++i) rec[i] = hdr[i];
-    sh_kb = Kb;
   }
   __syncthreads();
   const double Kb = sh_kb;
+  if (a.scheme == CRT_SCHEME_ZQ) {
+    // tau_i = tau_d(dlai_mean), always 'quad' (_solve_zq.py:51): one node per thread, then the same tree reduction
+    const double dlm = sh_dlm;
+    for (int q = tid; q < NQT; q += K0_BLOCK) pmb[q] = qc.w2sc[q] * exp(-kq[q] * dlm);
+    __syncthreads();
+    if (wave == 0) {
+      const double t = wave_sum64(pmb[lane] + (lane < NQT - 64 ? pmb[64 + lane] : 0.0));
+      if (lane == 0) rec[S_TAUI] = t;
+    }
+  }
 
   double* v = rec + REC_HDR;
   for (int j = tid; j < nz; j += K0_BLOCK) {

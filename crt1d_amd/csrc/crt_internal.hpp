@@ -61,18 +61,31 @@ struct ColArgs {
   double* ws;  // [ncol][rec_len]
 };
 
+// Spectra and output profiles are stored as TIO = double (crt_hip_*_f64) or float (crt_hip_*_f32); the per-column
+// geometry, the K0 records and ALL arithmetic are fp64 in both cases (the f32 entry points halve the HBM bytes, they
+// do not lower the precision of the solve: results are the fp64 results rounded once to fp32).
 struct SolveArgs {
   int ncol, nb, nz, reclen;
   long long col_stride;
   const double* ws;  // K0 records
-  const double* I_dr0;
-  const double* I_df0;
-  const double* leaf_r;
-  const double* leaf_t;
-  const double* soil_r;
-  double* o[7];  // I_dr, I_df_d, I_df_u, F, x0, x1, x2
+  const void* I_dr0;
+  const void* I_df0;
+  const void* leaf_r;
+  const void* leaf_t;
+  const void* soil_r;
+  void* o[7];  // I_dr, I_df_d, I_df_u, F, x0, x1, x2
   double mu_s;
+  int f32;     // 0: TIO = double, 1: TIO = float
 };
+
+template <typename TIO>
+__device__ inline double ldio(const void* p, long long i) {
+  return (double)reinterpret_cast<const TIO*>(p)[i];
+}
+template <typename TIO>
+__device__ inline TIO* outp(void* p) {
+  return reinterpret_cast<TIO*>(p);
+}
 
 // ------------------------------------------------------------------------------------------
 // G(psi) closed forms on device (crt1d/leaf_angle.py:118-202); `cs`, `sn` = cos/sin(psi).
@@ -158,26 +171,16 @@ __device__ inline const double* stage_records(const SolveArgs& a, const Item& it
 }
 
 // streaming (write-once) stores: outputs are never re-read by the kernel
-template <int VEC>
-struct Pack;
-template <>
-struct Pack<1> {
-  typedef double type;
-};
-template <>
-struct Pack<2> {
-  typedef double type __attribute__((ext_vector_type(2)));
-};
-
-template <int VEC>
-__device__ inline void store_stream(double* p, const double (&v)[VEC]) {
+template <typename TIO, int VEC>
+__device__ inline void store_stream(TIO* p, const double (&v)[VEC]) {
   if constexpr (VEC == 1) {
-    __builtin_nontemporal_store(v[0], p);
+    __builtin_nontemporal_store((TIO)v[0], p);
   } else {
-    typename Pack<2>::type t;
-    t.x = v[0];
-    t.y = v[1];
-    __builtin_nontemporal_store(t, reinterpret_cast<typename Pack<2>::type*>(p));
+    typedef TIO vt __attribute__((ext_vector_type(2)));
+    vt t;
+    t.x = (TIO)v[0];
+    t.y = (TIO)v[1];
+    __builtin_nontemporal_store(t, reinterpret_cast<vt*>(p));
   }
 }
 

@@ -31,14 +31,15 @@ struct BandIn {
   double I_dr0, I_df0, r, t, s;
 };
 
+template <typename TIO>
 __device__ inline BandIn load_band(const SolveArgs& a, int c, int b, bool need_soil) {
   const long long i = (long long)c * a.col_stride + b;
   BandIn in;
-  in.I_dr0 = a.I_dr0[i];
-  in.I_df0 = a.I_df0[i];
-  in.r = a.leaf_r[i];
-  in.t = a.leaf_t[i];
-  in.s = need_soil ? a.soil_r[i] : 0.0;
+  in.I_dr0 = ldio<TIO>(a.I_dr0, i);
+  in.I_df0 = ldio<TIO>(a.I_df0, i);
+  in.r = ldio<TIO>(a.leaf_r, i);
+  in.t = ldio<TIO>(a.leaf_t, i);
+  in.s = need_soil ? ldio<TIO>(a.soil_r, i) : 0.0;
   return in;
 }
 
@@ -470,7 +471,7 @@ struct Sch4s {
 // k_direct: lanes store their own band(s) per level (fallback for small nb)
 constexpr int DBLOCK = 256;
 
-template <class S, int VEC, bool USE_LDS>
+template <class S, typename TIO, int VEC, bool USE_LDS>
 __global__ __launch_bounds__(DBLOCK) void k_direct(SolveArgs a) {
   extern __shared__ double lds[];
   const Item it = locate<DBLOCK, VEC>(a.ncol, a.nb);
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(DBLOCK) void k_direct(SolveArgs a) {
   if (!it.active) return;
   S st[VEC];
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) st[v].init(rec, load_band(a, it.c, it.b + v, S::SOIL), a);
+  for (int v = 0; v < VEC; ++v) st[v].init(rec, load_band<TIO>(a, it.c, it.b + v, S::SOIL), a);
   const int nz = a.nz;
   long long o = ((long long)it.c * nz) * a.nb + it.b;
   for (int j = 0; j < nz; ++j, o += a.nb) {
@@ -490,15 +491,13 @@ __global__ __launch_bounds__(DBLOCK) void k_direct(SolveArgs a) {
       double pk[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) pk[v] = val[v][k];
-      store_stream<VEC>(a.o[k] + o, pk);
+      store_stream<TIO, VEC>(outp<TIO>(a.o[k]) + o, pk);
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // k_tile: workgroup = CB whole columns; T levels staged in LDS, flushed as contiguous aligned runs
-typedef double d2 __attribute__((ext_vector_type(2)));
-
 struct TileCfg {
   int CB;        // columns per workgroup
   int T;         // levels per LDS tile
@@ -511,8 +510,10 @@ struct TileCfg {
 // the tile protocol only needs the LDS writes/reads of the other waves to have completed.
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <class S, int MAXT>
+template <class S, typename TIO, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {
+  constexpr int VW = 16 / (int)sizeof(TIO);  // elements per 16-B store: 2 doubles / 4 floats
+  typedef TIO vt __attribute__((ext_vector_type(VW)));
   extern __shared__ double lds[];
   const int nb = a.nb, nz = a.nz, CB = cfg.CB, T = cfg.T;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -525,51 +526,51 @@ __global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {
     for (int i = tid; i < n; i += nthr) lds[i] = src[i];
   }
   __syncthreads();
-  double* tile = lds + cfg.rec_dbl;  // [NARR][CB][T][nb]
+  TIO* tile = reinterpret_cast<TIO*>(lds + cfg.rec_dbl);  // [NARR][CB][T][nb]
   const int cl = tid / nb, b = tid - cl * nb;
   const bool active = cl < ncb;
   const double* rec = lds + (active ? cl : 0) * a.reclen;
   S st;
-  if (active) st.init(rec, load_band(a, c0 + cl, b, S::SOIL), a);
-  const int colrun = T * nb;  // doubles per (array, column) slot of the tile
+  if (active) st.init(rec, load_band<TIO>(a, c0 + cl, b, S::SOIL), a);
+  const int colrun = T * nb;  // elements per (array, column) slot of the tile
 
   for (int j0 = 0; j0 < nz; j0 += T) {
     const int Tc = min(T, nz - j0);
     if (active) {
-      double* tl = tile + cl * colrun + b;
+      TIO* tl = tile + cl * colrun + b;
       for (int t = 0; t < Tc; ++t) {
         double val[S::NARR];
         st.level(j0 + t, rec, nz, val);
 #pragma unroll
-        for (int k = 0; k < S::NARR; ++k) tl[k * (CB * colrun) + t * nb] = val[k];
+        for (int k = 0; k < S::NARR; ++k) tl[k * (CB * colrun) + t * nb] = (TIO)val[k];
       }
     }
     if (cfg.flags & 1) __syncthreads(); else lds_barrier();
-    // flush: per (array, column) one contiguous run of Tc * nb doubles
+    // flush: per (array, column) one contiguous run of Tc * nb elements
     const int n = Tc * nb;
     for (int k = 0; k < S::NARR; ++k) {
       for (int q = 0; q < ncb; ++q) {
-        double* g = a.o[k] + ((long long)(c0 + q) * nz + j0) * nb;
-        const double* s = tile + k * (CB * colrun) + q * colrun;
-        const int mis = (int)((reinterpret_cast<uintptr_t>(g) >> 3) & 1);  // run starts on an odd double?
-        const int npair = (n - mis) >> 1;
+        TIO* g = outp<TIO>(a.o[k]) + ((long long)(c0 + q) * nz + j0) * nb;
+        const TIO* s = tile + k * (CB * colrun) + q * colrun;
+        // leading elements up to the next 16-B boundary of the destination
+        int mis = (int)(((16 - (reinterpret_cast<uintptr_t>(g) & 15)) & 15) / sizeof(TIO));
+        if (mis > n) mis = n;
+        const int nvec = (n - mis) / VW;
+        const int tail = (n - mis) - nvec * VW;
+        vt* gv = reinterpret_cast<vt*>(g + mis);
         if ((reinterpret_cast<uintptr_t>(s + mis) & 15) == 0) {
-          const d2* s2 = reinterpret_cast<const d2*>(s + mis);
-          d2* g2 = reinterpret_cast<d2*>(g + mis);
-          for (int i = tid; i < npair; i += nthr) g2[i] = s2[i];
+          const vt* sv = reinterpret_cast<const vt*>(s + mis);
+          for (int i = tid; i < nvec; i += nthr) gv[i] = sv[i];
         } else {
-          d2* g2 = reinterpret_cast<d2*>(g + mis);
-          for (int i = tid; i < npair; i += nthr) {
-            d2 v;
-            v.x = s[mis + 2 * i];
-            v.y = s[mis + 2 * i + 1];
-            g2[i] = v;
+          for (int i = tid; i < nvec; i += nthr) {
+            vt v;
+#pragma unroll
+            for (int w = 0; w < VW; ++w) v[w] = s[mis + VW * i + w];
+            gv[i] = v;
           }
         }
-        if (tid == 0) {
-          if (mis) g[0] = s[0];
-          if ((n - mis) & 1) g[n - 1] = s[n - 1];
-        }
+        if (tid < mis) g[tid] = s[tid];
+        if (tid < tail) g[mis + nvec * VW + tid] = s[mis + nvec * VW + tid];
       }
     }
     if (cfg.flags & 1) __syncthreads(); else lds_barrier();
@@ -586,15 +587,16 @@ int g_tune[8] = {78 * 1024, 0, 0, 0, 0, 0, 0, 0};
 
 int gcd(int x, int y) { return y ? gcd(y, x % y) : x; }
 
-template <class S>
+template <class S, typename TIO>
 int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
   done = false;
   const int nb = a.nb;
   if (nb < 64 || nb > 1024) return CRT_OK;
   const int CB = nb <= 256 ? 256 / nb : 1;
   const int nthr = CB > 1 ? 256 : ((nb + 63) / 64) * 64;
-  const int Ta = 16 / gcd(nb, 16);  // levels per line-aligned run
-  const size_t per_level = (size_t)S::NARR * CB * nb * sizeof(double);
+  const int line = 128 / (int)sizeof(TIO);  // elements per 128-B line
+  const int Ta = line / gcd(nb, line);      // levels per line-aligned run
+  const size_t per_level = (size_t)S::NARR * CB * nb * sizeof(TIO);
   const size_t target = (size_t)g_tune[0];
   int T = Ta;
   if (per_level * Ta > target) {
@@ -611,49 +613,56 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
   cfg.T = T;
   cfg.rec_dbl = (CB * a.reclen + 1) & ~1;
   cfg.flags = g_tune[2];
-  const size_t sh = (cfg.rec_dbl + (size_t)S::NARR * CB * T * nb) * sizeof(double);
+  const size_t sh = cfg.rec_dbl * sizeof(double) + (size_t)S::NARR * CB * T * nb * sizeof(TIO);
   if (sh > 160 * 1024) return CRT_OK;
   if (sh > 64 * 1024) {
-    const void* fn = nthr <= 256 ? (const void*)k_tile<S, 256> : nthr <= 512 ? (const void*)k_tile<S, 512> : (const void*)k_tile<S, 1024>;
+    const void* fn = nthr <= 256 ? (const void*)k_tile<S, TIO, 256> : nthr <= 512 ? (const void*)k_tile<S, TIO, 512>
+                                                                                   : (const void*)k_tile<S, TIO, 1024>;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return CRT_ERR_LAUNCH;
   }
   const int grid = (a.ncol + CB - 1) / CB;
   if (nthr <= 256)
-    hipLaunchKernelGGL((k_tile<S, 256>), dim3(grid), dim3(nthr), sh, s, a, cfg);
+    hipLaunchKernelGGL((k_tile<S, TIO, 256>), dim3(grid), dim3(nthr), sh, s, a, cfg);
   else if (nthr <= 512)
-    hipLaunchKernelGGL((k_tile<S, 512>), dim3(grid), dim3(nthr), sh, s, a, cfg);
+    hipLaunchKernelGGL((k_tile<S, TIO, 512>), dim3(grid), dim3(nthr), sh, s, a, cfg);
   else
-    hipLaunchKernelGGL((k_tile<S, 1024>), dim3(grid), dim3(nthr), sh, s, a, cfg);
+    hipLaunchKernelGGL((k_tile<S, TIO, 1024>), dim3(grid), dim3(nthr), sh, s, a, cfg);
   done = true;
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 
-template <class S, int VEC, bool USE_LDS>
+template <class S, typename TIO, int VEC, bool USE_LDS>
 int launch_direct_v(const SolveArgs& a, size_t lds_bytes, hipStream_t s) {
   const long long items = (long long)a.ncol * (a.nb / VEC);
   const long long nblk = (items + DBLOCK - 1) / DBLOCK;
   if (nblk > 0x7fffffffLL) return CRT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((k_direct<S, VEC, USE_LDS>), dim3((unsigned)nblk), dim3(DBLOCK), USE_LDS ? lds_bytes : 0, s, a);
+  hipLaunchKernelGGL((k_direct<S, TIO, VEC, USE_LDS>), dim3((unsigned)nblk), dim3(DBLOCK), USE_LDS ? lds_bytes : 0, s, a);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 
-template <class S>
+template <class S, typename TIO>
 int launch_scheme(const SolveArgs& a, hipStream_t s, int force) {
   if (force != 1) {
     bool done;
-    int st = launch_tile<S>(a, s, done);
+    int st = launch_tile<S, TIO>(a, s, done);
     if (st != CRT_OK || done) return st;
   }
-  // two bands per lane (16-B stores) when rows keep 16-B alignment, else one
+  // two bands per lane when rows keep the alignment of a 2-element vector, else one
   bool vec2 = (a.nb % 2 == 0) && (a.col_stride % 2 == 0);
   for (int i = 0; i < S::NARR && vec2; ++i)
-    if (reinterpret_cast<uintptr_t>(a.o[i]) & 15) vec2 = false;
+    if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) vec2 = false;
   const int nbv = a.nb / (vec2 ? 2 : 1);
   const long long cols_per_block = (DBLOCK - 1) / nbv + 2;
   const size_t lds_bytes = (size_t)cols_per_block * a.reclen * sizeof(double);
   const bool use_lds = lds_bytes <= (size_t)MAX_DIRECT_LDS;
-  if (vec2) return use_lds ? launch_direct_v<S, 2, true>(a, lds_bytes, s) : launch_direct_v<S, 2, false>(a, lds_bytes, s);
-  return use_lds ? launch_direct_v<S, 1, true>(a, lds_bytes, s) : launch_direct_v<S, 1, false>(a, lds_bytes, s);
+  if (vec2)
+    return use_lds ? launch_direct_v<S, TIO, 2, true>(a, lds_bytes, s) : launch_direct_v<S, TIO, 2, false>(a, lds_bytes, s);
+  return use_lds ? launch_direct_v<S, TIO, 1, true>(a, lds_bytes, s) : launch_direct_v<S, TIO, 1, false>(a, lds_bytes, s);
+}
+
+template <class S>
+int launch_io(const SolveArgs& a, hipStream_t s, int force) {
+  return a.f32 ? launch_scheme<S, float>(a, s, force) : launch_scheme<S, double>(a, s, force);
 }
 
 }  // namespace
@@ -665,11 +674,11 @@ void tune_closed(int key, int value) {
 // force: 0 = pick (tile when it applies), 1 = direct-store kernel (kept selectable for A/B measurements)
 int launch_closed(int scheme, const SolveArgs& a, hipStream_t s, int force) {
   switch (scheme) {
-    case CRT_SCHEME_2S: return launch_scheme<Sch2s>(a, s, force);
-    case CRT_SCHEME_4S: return launch_scheme<Sch4s>(a, s, force);
-    case CRT_SCHEME_BL: return launch_scheme<SchBl>(a, s, force);
-    case CRT_SCHEME_G77: return launch_scheme<SchG77<false>>(a, s, force);
-    case CRT_SCHEME_BF: return launch_scheme<SchG77<true>>(a, s, force);
+    case CRT_SCHEME_2S: return launch_io<Sch2s>(a, s, force);
+    case CRT_SCHEME_4S: return launch_io<Sch4s>(a, s, force);
+    case CRT_SCHEME_BL: return launch_io<SchBl>(a, s, force);
+    case CRT_SCHEME_G77: return launch_io<SchG77<false>>(a, s, force);
+    case CRT_SCHEME_BF: return launch_io<SchG77<true>>(a, s, force);
     default: return CRT_ERR_BAD_ARG;
   }
 }

@@ -34,7 +34,7 @@ struct EF {
 
 // ------------------------------------------------------------------------------------------
 // n79: crt1d/solvers/_solve_n79.py:70-155
-template <bool USE_LDS>
+template <typename TIO, bool USE_LDS>
 __global__ __launch_bounds__(TB) void k_n79(SolveArgs a, int rec_lds_doubles) {
   extern __shared__ double lds[];
   const Item it = locate<TB, 1>(a.ncol, a.nb);
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(TB) void k_n79(SolveArgs a, int rec_lds_doubles) {
 
   const int nz = a.nz, nb = a.nb;
   const long long ib = (long long)it.c * a.col_stride + it.b;
-  const double swb = a.I_dr0[ib], swd = a.I_df0[ib], rho = a.leaf_r[ib], tau = a.leaf_t[ib], alb = a.soil_r[ib];
+  const double swb = ldio<TIO>(a.I_dr0, ib), swd = ldio<TIO>(a.I_df0, ib), rho = ldio<TIO>(a.leaf_r, ib), tau = ldio<TIO>(a.leaf_t, ib), alb = ldio<TIO>(a.soil_r, ib);
   const double invmu = rec[S_INVMU];
   const double* tbcum = rec + REC_HDR;
   const double* tb = tbcum + nz;
@@ -107,10 +107,10 @@ __global__ __launch_bounds__(TB) void k_n79(SolveArgs a, int rec_lds_doubles) {
   long long om = ((long long)it.c * (nz - 1) + (nz - 2)) * nb + it.b;
   {
     const double idr = swb * tbcum[nz - 1];
-    __builtin_nontemporal_store(idr, a.o[0] + o);
-    __builtin_nontemporal_store(dn, a.o[1] + o);
-    __builtin_nontemporal_store(up, a.o[2] + o);
-    __builtin_nontemporal_store(idr * invmu + 2 * dn + 2 * up, a.o[3] + o);
+    __builtin_nontemporal_store((TIO)(idr), outp<TIO>(a.o[0]) + o);
+    __builtin_nontemporal_store((TIO)(dn), outp<TIO>(a.o[1]) + o);
+    __builtin_nontemporal_store((TIO)(up), outp<TIO>(a.o[2]) + o);
+    __builtin_nontemporal_store((TIO)(idr * invmu + 2 * dn + 2 * up), outp<TIO>(a.o[3]) + o);
   }
   for (int k = nz - 2; k >= 0; --k) {
     o -= nb;
@@ -128,20 +128,20 @@ __global__ __launch_bounds__(TB) void k_n79(SolveArgs a, int rec_lds_doubles) {
     const double direct = src * oma;
     const double diffuse = (dn1 + up) * (1 - t) * oma;
     const double fs = fsun[k];
-    __builtin_nontemporal_store((diffuse * fs + direct) * isl[k], a.o[4] + om);
-    __builtin_nontemporal_store((diffuse * (1 - fs)) * ish[k], a.o[5] + om);
+    __builtin_nontemporal_store((TIO)((diffuse * fs + direct) * isl[k]), outp<TIO>(a.o[4]) + om);
+    __builtin_nontemporal_store((TIO)((diffuse * (1 - fs)) * ish[k]), outp<TIO>(a.o[5]) + om);
     om -= nb;
     const double idr = swb * tbcum[k];
-    __builtin_nontemporal_store(idr, a.o[0] + o);
-    __builtin_nontemporal_store(dn, a.o[1] + o);
-    __builtin_nontemporal_store(up, a.o[2] + o);
-    __builtin_nontemporal_store(idr * invmu + 2 * dn + 2 * up, a.o[3] + o);
+    __builtin_nontemporal_store((TIO)(idr), outp<TIO>(a.o[0]) + o);
+    __builtin_nontemporal_store((TIO)(dn), outp<TIO>(a.o[1]) + o);
+    __builtin_nontemporal_store((TIO)(up), outp<TIO>(a.o[2]) + o);
+    __builtin_nontemporal_store((TIO)(idr * invmu + 2 * dn + 2 * up), outp<TIO>(a.o[3]) + o);
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // zq: crt1d/solvers/_solve_zq.py:74-219
-template <bool USE_LDS>
+template <typename TIO, bool USE_LDS>
 __global__ __launch_bounds__(TB) void k_zq(SolveArgs a, int rec_lds_doubles) {
   extern __shared__ double lds[];
   const Item it = locate<TB, 1>(a.ncol, a.nb);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(TB) void k_zq(SolveArgs a, int rec_lds_doubles) {
 
   const int m = a.nz, nb = a.nb;
   const long long ib = (long long)it.c * a.col_stride + it.b;
-  const double I_dr0 = a.I_dr0[ib], I_df0 = a.I_df0[ib], bL = a.leaf_r[ib], tL = a.leaf_t[ib], rho = a.soil_r[ib];
+  const double I_dr0 = ldio<TIO>(a.I_dr0, ib), I_df0 = ldio<TIO>(a.I_df0, ib), bL = ldio<TIO>(a.leaf_r, ib), tL = ldio<TIO>(a.leaf_t, ib), rho = ldio<TIO>(a.soil_r, ib);
   const double mu = rec[S_MU], invmu = rec[S_INVMU], t = rec[S_TAUI], t_psi = rec[S_TPSI];
   const double* ekl = rec + REC_HDR;
 
@@ -215,13 +215,13 @@ __global__ __launch_bounds__(TB) void k_zq(SolveArgs a, int rec_lds_doubles) {
     const double up = (xul + qlo * xd) * iden;
     const double Fss = S * invmu + 2 * xul + 2 * xd;
     const double F = S * invmu + 2 * up + 2 * dn;
-    __builtin_nontemporal_store(S, a.o[0] + o);     // :219
-    __builtin_nontemporal_store(dn, a.o[1] + o);    // :198
-    __builtin_nontemporal_store(up, a.o[2] + o);    // :200
-    __builtin_nontemporal_store(F, a.o[3] + o);     // :202
-    __builtin_nontemporal_store(xd, a.o[4] + o);    // I_df_d_ss :197
-    __builtin_nontemporal_store(xul, a.o[5] + o);   // I_df_u_ss :199
-    __builtin_nontemporal_store(Fss, a.o[6] + o);   // :201
+    __builtin_nontemporal_store((TIO)(S), outp<TIO>(a.o[0]) + o);     // :219
+    __builtin_nontemporal_store((TIO)(dn), outp<TIO>(a.o[1]) + o);    // :198
+    __builtin_nontemporal_store((TIO)(up), outp<TIO>(a.o[2]) + o);    // :200
+    __builtin_nontemporal_store((TIO)(F), outp<TIO>(a.o[3]) + o);     // :202
+    __builtin_nontemporal_store((TIO)(xd), outp<TIO>(a.o[4]) + o);    // I_df_d_ss :197
+    __builtin_nontemporal_store((TIO)(xul), outp<TIO>(a.o[5]) + o);   // I_df_u_ss :199
+    __builtin_nontemporal_store((TIO)(Fss), outp<TIO>(a.o[6]) + o);   // :201
     xd = xdl;
     xu = xul;
   }
@@ -240,7 +240,8 @@ int set_lds_limit(K kern, size_t bytes) {
 
 }  // namespace
 
-int launch_tridiag(int scheme, const SolveArgs& a, hipStream_t s, int force) {
+template <typename TIO>
+int launch_tridiag_io(int scheme, const SolveArgs& a, hipStream_t s, int force) {
   if (force != 1) {  // column-tile kernel (solve_tridiag_tile.hip) when it applies; force = 1 keeps the per-wave kernels
     bool done = false;
     const int st = launch_tridiag_tile(scheme, a, s, done);
@@ -261,24 +262,28 @@ int launch_tridiag(int scheme, const SolveArgs& a, hipStream_t s, int force) {
   int st;
   if (scheme == CRT_SCHEME_N79) {
     if (use_lds) {
-      if ((st = set_lds_limit(k_n79<true>, sh)) != CRT_OK) return st;
-      hipLaunchKernelGGL(k_n79<true>, grid, block, sh, s, a, (int)rec_doubles);
+      if ((st = set_lds_limit(k_n79<TIO, true>, sh)) != CRT_OK) return st;
+      hipLaunchKernelGGL((k_n79<TIO, true>), grid, block, sh, s, a, (int)rec_doubles);
     } else {
-      if ((st = set_lds_limit(k_n79<false>, sh)) != CRT_OK) return st;
-      hipLaunchKernelGGL(k_n79<false>, grid, block, sh, s, a, 0);
+      if ((st = set_lds_limit(k_n79<TIO, false>, sh)) != CRT_OK) return st;
+      hipLaunchKernelGGL((k_n79<TIO, false>), grid, block, sh, s, a, 0);
     }
   } else if (scheme == CRT_SCHEME_ZQ) {
     if (use_lds) {
-      if ((st = set_lds_limit(k_zq<true>, sh)) != CRT_OK) return st;
-      hipLaunchKernelGGL(k_zq<true>, grid, block, sh, s, a, (int)rec_doubles);
+      if ((st = set_lds_limit(k_zq<TIO, true>, sh)) != CRT_OK) return st;
+      hipLaunchKernelGGL((k_zq<TIO, true>), grid, block, sh, s, a, (int)rec_doubles);
     } else {
-      if ((st = set_lds_limit(k_zq<false>, sh)) != CRT_OK) return st;
-      hipLaunchKernelGGL(k_zq<false>, grid, block, sh, s, a, 0);
+      if ((st = set_lds_limit(k_zq<TIO, false>, sh)) != CRT_OK) return st;
+      hipLaunchKernelGGL((k_zq<TIO, false>), grid, block, sh, s, a, 0);
     }
   } else {
     return CRT_ERR_BAD_ARG;
   }
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+}
+
+int launch_tridiag(int scheme, const SolveArgs& a, hipStream_t s, int force) {
+  return a.f32 ? launch_tridiag_io<float>(scheme, a, s, force) : launch_tridiag_io<double>(scheme, a, s, force);
 }
 
 }  // namespace crt

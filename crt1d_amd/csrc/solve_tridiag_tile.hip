@@ -45,13 +45,14 @@ struct TriN79 {
   __host__ __device__ static inline int out_rows(int arr, int nz) { return arr >= 4 ? nz - 1 : nz; }
   __device__ inline double band_const() const { return swb; }
 
+  template <typename TIO>
   __device__ inline void init(const double* rec, const SolveArgs& a, int c, int b) {
     const long long i = (long long)c * a.col_stride + b;
-    swb = a.I_dr0[i];
-    swd = a.I_df0[i];
-    rho = a.leaf_r[i];
-    tau = a.leaf_t[i];
-    alb = a.soil_r[i];
+    swb = ldio<TIO>(a.I_dr0, i);
+    swd = ldio<TIO>(a.I_df0, i);
+    rho = ldio<TIO>(a.leaf_r, i);
+    tau = ldio<TIO>(a.leaf_t, i);
+    alb = ldio<TIO>(a.soil_r, i);
     oma = 1 - (rho + tau);  // :56,145
     invmu = rec[S_INVMU];
   }
@@ -155,12 +156,13 @@ struct TriZq {
   __host__ __device__ static inline int out_rows(int, int nz) { return nz; }
   __device__ inline double band_const() const { return I_dr0; }
 
+  template <typename TIO>
   __device__ inline void init(const double* rec, const SolveArgs& a, int c, int b) {
     const long long i = (long long)c * a.col_stride + b;
-    I_dr0 = a.I_dr0[i];
-    I_df0 = a.I_df0[i];
-    const double bL = a.leaf_r[i], tL = a.leaf_t[i];
-    rho = a.soil_r[i];
+    I_dr0 = ldio<TIO>(a.I_dr0, i);
+    I_df0 = ldio<TIO>(a.I_df0, i);
+    const double bL = ldio<TIO>(a.leaf_r, i), tL = ldio<TIO>(a.leaf_t, i);
+    rho = ldio<TIO>(a.soil_r, i);
     const double mu = rec[S_MU], t = rec[S_TAUI], t_psi = rec[S_TPSI];
     invmu = rec[S_INVMU];
     const double aL = 1 - (bL + tL);                                             // :87
@@ -247,15 +249,16 @@ struct TriZq {
 
 // ------------------------------------------------------------------------------------------
 // flush one output array: rows [j0, j0 + nrows) of column c, one contiguous run
-template <class S, int ARR>
+template <class S, typename TIO, int ARR>
 __device__ inline void flush_array(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride,
                                    int c, int j0, int nrows, double invmu, float inv_nb) {
   if (nrows <= 0) return;
+  typedef TIO vt __attribute__((ext_vector_type(2)));
   const int nb = a.nb, nz = a.nz;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int n = nrows * nb;
-  double* g = a.o[ARR] + ((long long)c * S::out_rows(ARR, nz) + j0) * nb;
-  const int mis = (int)((reinterpret_cast<uintptr_t>(g) >> 3) & 1);
+  TIO* g = outp<TIO>(a.o[ARR]) + ((long long)c * S::out_rows(ARR, nz) + j0) * nb;
+  const int mis = (int)((reinterpret_cast<uintptr_t>(g) / sizeof(TIO)) & 1);  // run starts on an odd element?
   const int npair = (n - mis) >> 1;
   auto elem = [&](int i) -> double {
     if constexpr (S::derived(ARR)) {
@@ -268,25 +271,25 @@ __device__ inline void flush_array(const SolveArgs& a, const double* rec, const 
       return tile[S::staged_slot(ARR) * tstride + i];
     }
   };
-  d2* g2 = reinterpret_cast<d2*>(g + mis);
+  vt* g2 = reinterpret_cast<vt*>(g + mis);
   for (int i = tid; i < npair; i += nthr) {
-    d2 v;
-    v.x = elem(mis + 2 * i);
-    v.y = elem(mis + 2 * i + 1);
+    vt v;
+    v.x = (TIO)elem(mis + 2 * i);
+    v.y = (TIO)elem(mis + 2 * i + 1);
     g2[i] = v;
   }
   if (tid == 0) {
-    if (mis) g[0] = elem(0);
-    if ((n - mis) & 1) g[n - 1] = elem(n - 1);
+    if (mis) g[0] = (TIO)elem(0);
+    if ((n - mis) & 1) g[n - 1] = (TIO)elem(n - 1);
   }
 }
 
-template <class S, int ARR>
+template <class S, typename TIO, int ARR>
 __device__ inline void flush_arrays(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride, int c,
                                     int j0, int T, double invmu, float inv_nb) {
   const int nr = min(j0 + T, S::out_rows(ARR, a.nz)) - j0;
-  flush_array<S, ARR>(a, rec, bandc, tile, tstride, c, j0, nr, invmu, inv_nb);
-  if constexpr (ARR + 1 < S::NOUT) flush_arrays<S, ARR + 1>(a, rec, bandc, tile, tstride, c, j0, T, invmu, inv_nb);
+  flush_array<S, TIO, ARR>(a, rec, bandc, tile, tstride, c, j0, nr, invmu, inv_nb);
+  if constexpr (ARR + 1 < S::NOUT) flush_arrays<S, TIO, ARR + 1>(a, rec, bandc, tile, tstride, c, j0, T, invmu, inv_nb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -301,7 +304,7 @@ struct FlushMap {
   bool on;
 };
 
-template <class S, int T>
+template <class S, typename TIO, int T>
 __device__ inline void flush_fused(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int c, int j0,
                                    const FlushMap& fm, double invmu) {
   const int nb2 = a.nb >> 1, nz = a.nz;
@@ -317,7 +320,13 @@ __device__ inline void flush_fused(const SolveArgs& a, const double* rec, const 
 #pragma unroll
     for (int k = 0; k < S::NOUT; ++k) {
       const int rows = S::out_rows(k, nz);
-      if (j < rows) reinterpret_cast<d2*>(a.o[k])[((long long)c * rows + j) * nb2 + fm.p] = o[k];
+      if (j < rows) {
+        typedef TIO vt __attribute__((ext_vector_type(2)));
+        vt v;
+        v.x = (TIO)o[k].x;
+        v.y = (TIO)o[k].y;
+        reinterpret_cast<vt*>(a.o[k])[((long long)c * rows + j) * nb2 + fm.p] = v;
+      }
     }
   }
 }
@@ -325,7 +334,7 @@ __device__ inline void flush_fused(const SolveArgs& a, const double* rec, const 
 // ------------------------------------------------------------------------------------------
 // The segment loops are fully unrolled: the register-resident pairs be[M], bf[M] need static indices (a runtime-indexed
 // array goes to scratch; VGPR-index mode on vector types works but costs ~40 instructions per level, measured).
-template <class S, int M, int T, int MAXT, bool FUSED>
+template <class S, typename TIO, int M, int T, int MAXT, bool FUSED>
 __global__ __launch_bounds__(MAXT) void k_tri_tile(SolveArgs a, TriCfg cfg) {
   static_assert(M % T == 0, "tile height must divide the checkpoint spacing");
   extern __shared__ double lds[];
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(MAXT) void k_tri_tile(SolveArgs a, TriCfg cfg) {
   }
 
   S st;
-  st.init(rec, a, c, b);
+  st.template init<TIO>(rec, a, c, b);
   if (active) bandc[b] = st.band_const();
   const int K = S::rows(nz);
 
@@ -405,9 +414,9 @@ __global__ __launch_bounds__(MAXT) void k_tri_tile(SolveArgs a, TriCfg cfg) {
         if (k <= kend) {
           __syncthreads();
           if constexpr (FUSED)
-            flush_fused<S, T>(a, rec, bandc, tile, c, k, fm, invmu);
+            flush_fused<S, TIO, T>(a, rec, bandc, tile, c, k, fm, invmu);
           else
-            flush_arrays<S, 0>(a, rec, bandc, tile, tstride, c, k, T, invmu, inv_nb);
+            flush_arrays<S, TIO, 0>(a, rec, bandc, tile, tstride, c, k, T, invmu, inv_nb);
           __syncthreads();
         }
       }
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(MAXT) void k_tri_tile(SolveArgs a, TriCfg cfg) {
 
 constexpr size_t MAX_WG_LDS = 160 * 1024;
 
-template <class S, int M, int T, bool FUSED>
+template <class S, typename TIO, int M, int T, bool FUSED>
 int launch_mt(const SolveArgs& a, hipStream_t s, int nthr) {
   const int K = S::rows(a.nz);
   TriCfg cfg;
@@ -428,35 +437,35 @@ int launch_mt(const SolveArgs& a, hipStream_t s, int nthr) {
   cfg.off_tile = cfg.off_ck + 2 * cfg.nck * nthr;
   const size_t sh = ((size_t)cfg.off_tile + (size_t)S::NST * T * a.nb) * sizeof(double);
   if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
-  const void* fn = nthr <= 256 ? (const void*)k_tri_tile<S, M, T, 256, FUSED> : nthr <= 512 ? (const void*)k_tri_tile<S, M, T, 512, FUSED>
-                                                                                      : (const void*)k_tri_tile<S, M, T, 1024, FUSED>;
+  const void* fn = nthr <= 256 ? (const void*)k_tri_tile<S, TIO, M, T, 256, FUSED> : nthr <= 512 ? (const void*)k_tri_tile<S, TIO, M, T, 512, FUSED>
+                                                                                      : (const void*)k_tri_tile<S, TIO, M, T, 1024, FUSED>;
   if (sh > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
     return CRT_ERR_LAUNCH;
   dim3 grid(a.ncol), block(nthr);
   if (nthr <= 256)
-    hipLaunchKernelGGL((k_tri_tile<S, M, T, 256, FUSED>), grid, block, sh, s, a, cfg);
+    hipLaunchKernelGGL((k_tri_tile<S, TIO, M, T, 256, FUSED>), grid, block, sh, s, a, cfg);
   else if (nthr <= 512)
-    hipLaunchKernelGGL((k_tri_tile<S, M, T, 512, FUSED>), grid, block, sh, s, a, cfg);
+    hipLaunchKernelGGL((k_tri_tile<S, TIO, M, T, 512, FUSED>), grid, block, sh, s, a, cfg);
   else
-    hipLaunchKernelGGL((k_tri_tile<S, M, T, 1024, FUSED>), grid, block, sh, s, a, cfg);
+    hipLaunchKernelGGL((k_tri_tile<S, TIO, M, T, 1024, FUSED>), grid, block, sh, s, a, cfg);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 
 int g_tri_tune[4] = {0, 0, 0, 0};  // [0] force M (8/12/16), [1] force T (4/8)
 
 // instantiated (M, T) pairs
-template <class S, bool FUSED>
+template <class S, typename TIO, bool FUSED>
 int launch_cfg(const SolveArgs& a, hipStream_t s, int M, int T, int nthr) {
-  if (M == 8 && T == 4) return launch_mt<S, 8, 4, FUSED>(a, s, nthr);
-  if (M == 8 && T == 8) return launch_mt<S, 8, 8, FUSED>(a, s, nthr);
-  if (M == 12 && T == 4) return launch_mt<S, 12, 4, FUSED>(a, s, nthr);
-  if (M == 12 && T == 12) return launch_mt<S, 12, 12, FUSED>(a, s, nthr);
-  if (M == 16 && T == 4) return launch_mt<S, 16, 4, FUSED>(a, s, nthr);
-  if (M == 16 && T == 8) return launch_mt<S, 16, 8, FUSED>(a, s, nthr);
+  if (M == 8 && T == 4) return launch_mt<S, TIO, 8, 4, FUSED>(a, s, nthr);
+  if (M == 8 && T == 8) return launch_mt<S, TIO, 8, 8, FUSED>(a, s, nthr);
+  if (M == 12 && T == 4) return launch_mt<S, TIO, 12, 4, FUSED>(a, s, nthr);
+  if (M == 12 && T == 12) return launch_mt<S, TIO, 12, 12, FUSED>(a, s, nthr);
+  if (M == 16 && T == 4) return launch_mt<S, TIO, 16, 4, FUSED>(a, s, nthr);
+  if (M == 16 && T == 8) return launch_mt<S, TIO, 16, 8, FUSED>(a, s, nthr);
   return CRT_ERR_UNSUPPORTED;
 }
 
-template <class S>
+template <class S, typename TIO>
 int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done) {
   done = false;
   if (a.nb < 64 || a.nb > 1024) return CRT_OK;
@@ -489,8 +498,8 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done) {
   // fused flush needs even nb and 16-B aligned output arrays
   bool fused = (a.nb % 2 == 0);
   for (int i = 0; i < S::NOUT && fused; ++i)
-    if (reinterpret_cast<uintptr_t>(a.o[i]) & 15) fused = false;
-  const int st = fused ? launch_cfg<S, true>(a, s, M, T, nthr) : launch_cfg<S, false>(a, s, M, T, nthr);
+    if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) fused = false;
+  const int st = fused ? launch_cfg<S, TIO, true>(a, s, M, T, nthr) : launch_cfg<S, TIO, false>(a, s, M, T, nthr);
   if (st == CRT_ERR_UNSUPPORTED) return CRT_OK;
   done = st == CRT_OK;
   return st;
@@ -504,8 +513,8 @@ void tune_tridiag(int key, int value) {
 
 // returns CRT_OK with done = false when the column-tile kernel does not apply (caller falls back)
 int launch_tridiag_tile(int scheme, const SolveArgs& a, hipStream_t s, bool& done) {
-  if (scheme == CRT_SCHEME_N79) return launch_scheme<TriN79>(a, s, done);
-  if (scheme == CRT_SCHEME_ZQ) return launch_scheme<TriZq>(a, s, done);
+  if (scheme == CRT_SCHEME_N79) return a.f32 ? launch_scheme<TriN79, float>(a, s, done) : launch_scheme<TriN79, double>(a, s, done);
+  if (scheme == CRT_SCHEME_ZQ) return a.f32 ? launch_scheme<TriZq, float>(a, s, done) : launch_scheme<TriZq, double>(a, s, done);
   done = false;
   return CRT_ERR_BAD_ARG;
 }

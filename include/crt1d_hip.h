@@ -123,6 +123,28 @@ typedef struct crt_outputs {
   double* x2; /*                                zq: F_ss      | g77, bf: aI_l   */
 } crt_outputs;
 
+/* f32 storage variants: spectra read and profiles written as float (half the HBM bytes).  Geometry (crt_columns), the
+ * workspace and ALL arithmetic stay fp64: results are the fp64 results rounded once to fp32. */
+typedef struct crt_bands_f32 {
+  int32_t nb;
+  int64_t col_stride;
+  const float* I_dr0;
+  const float* I_df0;
+  const float* leaf_r;
+  const float* leaf_t;
+  const float* soil_r;
+} crt_bands_f32;
+
+typedef struct crt_outputs_f32 {
+  float* I_dr;
+  float* I_df_d;
+  float* I_df_u;
+  float* F;
+  float* x0;
+  float* x1;
+  float* x2;
+} crt_outputs_f32;
+
 int crt_hip_abi_version(void);
 const char* crt_hip_strerror(int status);
 
@@ -142,6 +164,16 @@ int crt_hip_zq_f64(const crt_columns*, const crt_bands*, const crt_options*, con
 int crt_hip_bl_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
 int crt_hip_g77_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
 int crt_hip_bf_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
+
+int crt_hip_solve_f32(int scheme, const crt_columns* cols, const crt_bands_f32* bands, const crt_options* opts,
+                      const crt_outputs_f32* out, void* workspace, size_t workspace_bytes, crt_stream_t stream);
+int crt_hip_2s_f32(const crt_columns*, const crt_bands_f32*, const crt_options*, const crt_outputs_f32*, void*, size_t, crt_stream_t);
+int crt_hip_4s_f32(const crt_columns*, const crt_bands_f32*, const crt_options*, const crt_outputs_f32*, void*, size_t, crt_stream_t);
+int crt_hip_n79_f32(const crt_columns*, const crt_bands_f32*, const crt_options*, const crt_outputs_f32*, void*, size_t, crt_stream_t);
+int crt_hip_zq_f32(const crt_columns*, const crt_bands_f32*, const crt_options*, const crt_outputs_f32*, void*, size_t, crt_stream_t);
+int crt_hip_bl_f32(const crt_columns*, const crt_bands_f32*, const crt_options*, const crt_outputs_f32*, void*, size_t, crt_stream_t);
+int crt_hip_g77_f32(const crt_columns*, const crt_bands_f32*, const crt_options*, const crt_outputs_f32*, void*, size_t, crt_stream_t);
+int crt_hip_bf_f32(const crt_columns*, const crt_bands_f32*, const crt_options*, const crt_outputs_f32*, void*, size_t, crt_stream_t);
 
 /*
  * Epilogue (model.py:573-647 `_calc_absorption` + diagnostics.py:39-108 `band`): layer absorption

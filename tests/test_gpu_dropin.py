@@ -183,3 +183,28 @@ def test_plan_flags_and_strided_outputs():
         assert not torch.equal(a[k], full[k])
     with pytest.raises(ValueError):
         batched.Plan("2s", cols, bands, workspace=torch.empty(16, dtype=torch.uint8, device="cuda"))
+
+
+@pytest.mark.parametrize("scheme", ["2s", "4s", "bl", "g77", "bf", "n79", "zq"])
+@pytest.mark.parametrize("shape", [(21, 300, 60), (5, 107, 61), (9, 64, 13), (40, 6, 20), (3, 130, 100)])
+def test_f32_storage_variant(scheme, shape):
+    """crt_hip_*_f32: float spectra in, float profiles out, fp64 arithmetic.  Feeding the SAME (float-representable)
+    inputs to the f64 entry point and rounding its outputs to float must give the identical bits (config 5:
+    'fp32 vs fp64 tolerance' -> the only difference is the final rounding, <= 2^-24 relative)."""
+    import torch
+
+    from crt1d_amd import batched, synth
+
+    ncol, nb, nz = shape
+    d = synth.make_columns(ncol, nb, nz, seed=17, uniform_dlai=(ncol % 2 == 1))
+    cols = batched.Columns.from_host(d)
+    b32 = batched.Bands.from_host({k: (d[k].astype(np.float32) if k in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r") else d[k]) for k in d})
+    assert b32.dtype == torch.float32
+    b64 = batched.Bands(*[None if t is None else t.double() for t in (b32.I_dr0, b32.I_df0, b32.leaf_r, b32.leaf_t, b32.soil_r)])
+    s32 = batched.solve(scheme, cols, b32)
+    s64 = batched.solve(scheme, cols, b64)
+    for k in s32:
+        assert s32[k].dtype == torch.float32 and s32[k].shape == s64[k].shape
+        assert torch.equal(s32[k], s64[k].float()), k
+    with pytest.raises(TypeError):
+        batched.Bands(b32.I_dr0, b64.I_df0, b32.leaf_r, b32.leaf_t, b32.soil_r)
