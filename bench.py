@@ -34,10 +34,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 # (each compulsory byte once: per-band inputs read, full profiles written)
 N_IO = {  # scheme: (n_in, n_full, n_mid)
     "2s": (5, 4, 0), "4s": (5, 4, 0), "bl": (4, 4, 0), "g77": (5, 7, 0), "bf": (5, 7, 0), "n79": (5, 4, 2), "zq": (5, 7, 0),
+    "zq_pa": (5, 4, 0),
 }
 # dominant kernel per scheme as rocprofv3 names it (template arguments abbreviated)
 KERNEL_NAMES = {"2s": "k_tile<Sch2s>", "4s": "k_tile<Sch4s>", "bl": "k_tile<SchBl>", "g77": "k_tile<SchG77<false>>",
-                "bf": "k_tile<SchG77<true>>", "n79": "k_tri_tile<TriN79>", "zq": "k_tri_tile<TriZq>"}
+                "bf": "k_tile<SchG77<true>>", "n79": "k_tri_tile<TriN79>", "zq": "k_tri_tile<TriZq>", "zq_pa": "k_tri_tile<TriZqPa> (+ k_zqpa_interp)"}
 
 
 def bytes_per_solve(scheme, nz, s=8):

@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcrt1d_hip.so")
 
 # enum crt_scheme
-SCHEME_IDS = {"2s": 0, "4s": 1, "n79": 2, "zq": 3, "bl": 4, "g77": 5, "bf": 6}
+SCHEME_IDS = {"2s": 0, "4s": 1, "n79": 2, "zq": 3, "bl": 4, "g77": 5, "bf": 6, "zq_pa": 7}
+F32_SCHEMES = ("2s", "4s", "n79", "zq", "bl", "g77", "bf")  # zq_pa: f64 only so far
 TAU_D_METHODS = {"quad": 0, "9sky": 1}
 NQ_TAU, NQ_G4, NQ_9SKY = 96, 32, 9
 NQ = NQ_TAU + NQ_G4 + NQ_9SKY
@@ -68,6 +69,7 @@ EXPORTS = [
     "crt_hip_abi_version",
     "crt_hip_strerror",
     "crt_hip_workspace_bytes",
+    "crt_hip_workspace_bytes_nb",
     "crt_hip_quad_nodes",
     "crt_hip_solve_f64",
     "crt_hip_2s_f64",
@@ -77,6 +79,7 @@ EXPORTS = [
     "crt_hip_bl_f64",
     "crt_hip_g77_f64",
     "crt_hip_bf_f64",
+    "crt_hip_zq_pa_f64",
     "crt_hip_solve_f32",
     "crt_hip_2s_f32",
     "crt_hip_4s_f32",
@@ -119,6 +122,8 @@ def load():
     lib.crt_hip_strerror.argtypes = [ctypes.c_int]
     lib.crt_hip_workspace_bytes.restype = ctypes.c_size_t
     lib.crt_hip_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int32, ctypes.c_int32]
+    lib.crt_hip_workspace_bytes_nb.restype = ctypes.c_size_t
+    lib.crt_hip_workspace_bytes_nb.argtypes = [ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
     lib.crt_hip_quad_nodes.restype = ctypes.c_int
     lib.crt_hip_quad_nodes.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
     solve_args = [
@@ -136,6 +141,8 @@ def load():
     lib.crt_hip_solve_f32.argtypes = [ctypes.c_int] + solve_args
     for s in SCHEME_IDS:
         for suffix in ("f64", "f32"):  # the f32 structs share the f64 layout (include/crt1d_hip.h)
+            if suffix == "f32" and s not in F32_SCHEMES:
+                continue
             f = getattr(lib, f"crt_hip_{s}_{suffix}")
             f.restype = ctypes.c_int
             f.argtypes = solve_args

@@ -29,6 +29,7 @@ OUT_KEYS = {
     "zq": ("I_dr", "I_df_d", "I_df_u", "F", "I_df_d_ss", "I_df_u_ss", "F_ss"),  # _solve_zq.py:221-229
     "g77": ("I_dr", "I_df_d", "I_df_u", "F", "aI_lsl", "aI_lsh", "aI_l"),  # _solve_g77.py:127-135
     "bf": ("I_dr", "I_df_d", "I_df_u", "F", "aI_lsl", "aI_lsh", "aI_l"),  # _solve_bf.py:144-153 (+ rho_c host-side)
+    "zq_pa": ("I_dr", "I_df_d", "I_df_u", "F"),  # _solve_zq_pa.py:413-418
 }
 _MID_KEYS = {"n79": ("aI_lsl", "aI_lsh")}  # (ncol, nz-1, nb)
 
@@ -184,8 +185,9 @@ class Bands:
         return cls(t("I_dr0"), t("I_df0"), t("leaf_r"), t("leaf_t"), t("soil_r"))
 
 
-def workspace_bytes(scheme, ncol, nz):
-    return int(_lib.load().crt_hip_workspace_bytes(_lib.SCHEME_IDS[scheme], ncol, nz))
+def workspace_bytes(scheme, ncol, nz, nb=1):
+    """Device workspace a solve needs; ``nb`` matters for zq_pa only (its computational-grid fluxes live there)."""
+    return int(_lib.load().crt_hip_workspace_bytes_nb(_lib.SCHEME_IDS[scheme], ncol, nz, nb))
 
 
 def alloc_outputs(scheme, ncol, nz, nb, device, dtype=torch.float64):
@@ -218,7 +220,7 @@ class Plan:
             v = self.out[k]
             if v.dtype != bands.dtype or not v.is_cuda or not v.is_contiguous():
                 raise TypeError(f"output {k!r} must be a contiguous CUDA tensor of dtype {bands.dtype}")
-        need = workspace_bytes(scheme, ncol, nz)
+        need = workspace_bytes(scheme, ncol, nz, nb)
         if workspace is None:
             workspace = torch.empty(need, dtype=torch.uint8, device=cols.device)
         elif workspace.numel() * workspace.element_size() < need:
@@ -230,6 +232,8 @@ class Plan:
         ptrs = [self.out[k].data_ptr() for k in OUT_KEYS[scheme]]
         ptrs += [None] * (7 - len(ptrs))
         self._out = _lib.CrtOutputs(*ptrs)
+        if bands.dtype == torch.float32 and scheme not in _lib.F32_SCHEMES:
+            raise TypeError(f"scheme {scheme!r} has no f32 storage variant yet")
         self._entry = f"crt_hip_{scheme}_{'f32' if bands.dtype == torch.float32 else 'f64'}"
         self._fn = getattr(self.lib, self._entry)
         self._wsb = workspace.numel() * workspace.element_size()

@@ -223,6 +223,13 @@ size_t crt_hip_workspace_bytes(int scheme, int32_t ncol, int32_t nz) {
   return (size_t)ncol * (size_t)rec_len(scheme, nz) * sizeof(double);
 }
 
+size_t crt_hip_workspace_bytes_nb(int scheme, int32_t ncol, int32_t nz, int32_t nb) {
+  size_t n = crt_hip_workspace_bytes(scheme, ncol, nz);
+  if (n == 0 || nb <= 0) return 0;
+  if (scheme == CRT_SCHEME_ZQ_PA) n += 2 * (size_t)ncol * (size_t)zqpa_M(nz) * (size_t)nb * sizeof(double);
+  return n;
+}
+
 int crt_hip_quad_nodes(double mu_s, double* psi_nodes) {
   if (!psi_nodes || !(mu_s > 0.0 && mu_s < 1.0)) return CRT_ERR_BAD_ARG;
   host_quad_nodes(mu_s, psi_nodes);
@@ -256,7 +263,7 @@ static int solve_impl(int scheme, const crt_columns* cols, const crt_bands* band
   }
   if (scheme == CRT_SCHEME_4S && !(mu_s > 0.0 && mu_s < 1.0)) return CRT_ERR_BAD_ARG;
   if (method != CRT_TAU_D_QUAD && method != CRT_TAU_D_9SKY) return CRT_ERR_BAD_ARG;  // ValueError, common.py:78
-  const size_t need = crt_hip_workspace_bytes(scheme, ncol, nz);
+  const size_t need = crt_hip_workspace_bytes_nb(scheme, ncol, nz, nb);
   if (!workspace || workspace_bytes < need) return CRT_ERR_WORKSPACE;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -301,6 +308,8 @@ static int solve_impl(int scheme, const crt_columns* cols, const crt_bands* band
   sa.o[6] = out->x2;
   sa.mu_s = mu_s;
   sa.f32 = f32;
+  if (scheme == CRT_SCHEME_ZQ_PA)
+    return launch_zqpa(sa, static_cast<double*>(workspace) + (size_t)ncol * sa.reclen, s);
   const int force = (flags & CRT_FLAG_DIRECT_STORES) ? 1 : 0;
   return tri ? launch_tridiag(scheme, sa, s, force) : launch_closed(scheme, sa, s, force);
 }
@@ -331,6 +340,7 @@ CRT_ENTRY(crt_hip_zq_f64, CRT_SCHEME_ZQ)
 CRT_ENTRY(crt_hip_bl_f64, CRT_SCHEME_BL)
 CRT_ENTRY(crt_hip_g77_f64, CRT_SCHEME_G77)
 CRT_ENTRY(crt_hip_bf_f64, CRT_SCHEME_BF)
+CRT_ENTRY(crt_hip_zq_pa_f64, CRT_SCHEME_ZQ_PA)
 #undef CRT_ENTRY
 
 #define CRT_ENTRY32(name, id)                                                                                      \

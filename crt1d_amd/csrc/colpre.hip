@@ -138,6 +138,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   __shared__ double pg[NQG];    // G-integral terms
   __shared__ double k9[CRT_NQ_9SKY];
   __shared__ double sh_kb, sh_dlm;
+  __shared__ double xis[104];  // zq_pa: cumulative LAI of the computational interfaces
 
   const int c = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
       rec[S_INVMU] = 1.0 / cs;
       rec[S_UNIF] = unif ? 1.0 : 0.0;
       rec[S_DL] = dl;
-      rec[14] = 0.0;
+      rec[S_M] = (double)zqpa_M(nz);
       rec[15] = 0.0;
       sh_kb = Kb;
       sh_dlm = dlm;
@@ -224,6 +225,29 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   }
   __syncthreads();
   const double Kb = sh_kb;
+  if (a.scheme == CRT_SCHEME_ZQ_PA) {
+    // computational grid of M equal layers (_solve_zq_pa.py:94-100): tau_d(LAI/M) (:176), exp(-K_b LAI/M) (:174)
+    const int M = zqpa_M(nz);
+    const double Lm = lai[0] / M;
+    for (int q = tid; q < NQT; q += K0_BLOCK) pmb[q] = qc.w2sc[q] * exp(-kq[q] * Lm);
+    __syncthreads();
+    if (wave == 0) {
+      const double t = wave_sum64(pmb[lane] + (lane < NQT - 64 ? pmb[64 + lane] : 0.0));
+      if (lane == 0) {
+        rec[S_TAUI] = t;
+        rec[S_TPSI] = exp(-Kb * Lm);
+        // xi[i] = cumulative LAI of computational interface i from the top, built by repeated addition as np.cumsum
+        // does (_solve_zq_pa.py:159): xi[0] = 0, xi[i] = xi[i-1] + Lm
+        double sacc = 0.0;
+        xis[0] = 0.0;
+        for (int i = 1; i <= M; ++i) {
+          sacc += Lm;
+          xis[i] = sacc;
+        }
+      }
+    }
+    __syncthreads();
+  }
   if (a.scheme == CRT_SCHEME_ZQ) {
     // tau_i = tau_d(dlai_mean), always 'quad' (_solve_zq.py:51): one node per thread, then the same tree reduction
     const double dlm = sh_dlm;
@@ -243,6 +267,23 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
       case CRT_SCHEME_ZQ:
         v[j] = ekl;
         break;
+      case CRT_SCHEME_ZQ_PA: {
+        const int M = zqpa_M(nz);
+        auto xi = [&](int i) { return xis[i]; };
+        // beam fraction seen by computational layer li = j+1 (:164-168): f_sl[li] = exp(-K_b xi[M+1-li])
+        v[j] = (j < M) ? exp(-Kb * xi(M - j)) : 0.0;
+        v[nz + j] = ekl;
+        // linear interpolation of the interface fluxes back to lai[j] (:357-362, np.interp semantics)
+        int lo = 0;
+        for (int i = 1; i < M; ++i)
+          if (xi(i) <= L) lo = i;
+        const double x0 = xi(lo), x1 = xi(lo + 1);
+        double w = (L - x0) / (x1 - x0);
+        if (L >= x1) w = 1.0;  // at or beyond the last node: np.interp returns fp[-1]
+        v[2 * nz + j] = (double)(M - lo);  // interface index (0 = ground) of the node above lai[j]
+        v[3 * nz + j] = w;
+        break;
+      }
       case CRT_SCHEME_BL:
         v[j] = L;
         v[nz + j] = ekl;

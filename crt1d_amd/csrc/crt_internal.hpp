@@ -18,6 +18,8 @@ namespace crt {
 //     n79             : tbcum = ekl, tb, td, fracsun, 1/(fracsun dlai), 1/(fracsha dlai)
 //                                                                     (_solve_n79.py:40-59)
 //     zq              : ekl                                           (_solve_zq.py:130)
+//     zq_pa           : beam fraction on the M computational layers, ekl, interpolation index, weight
+//                                                                     (_solve_zq_pa.py:159-168,357-362)
 enum RecScalar {
   S_KB = 0,     // K_b = G(psi)/cos(psi)              model.py:291-293
   S_MU = 1,     // cos(psi)
@@ -33,6 +35,7 @@ enum RecScalar {
   S_INVMU = 11, // 1/cos(psi)
   S_UNIF = 12,  // 1.0 when every dlai_j equals S_DL to within 4 ulp of LAI (all reference LAI generators), else 0.0
   S_DL = 13,    // (lai[0] - lai[nz-1]) / (nz - 1)
+  S_M = 14,     // zq_pa: number of computational layers min(100, nz)   _solve_zq_pa.py:95
   REC_HDR = 16
 };
 
@@ -40,6 +43,7 @@ __host__ __device__ inline int rec_nvec(int scheme) {
   switch (scheme) {
     case CRT_SCHEME_BL: return 3;
     case CRT_SCHEME_N79: return 6;
+    case CRT_SCHEME_ZQ_PA: return 4;
     case CRT_SCHEME_ZQ: return 1;
     default: return 2;
   }
@@ -206,6 +210,8 @@ int init_quadrature(hipStream_t s);
 void tune_closed(int key, int value);
 void tune_tridiag(int key, int value);
 int launch_tridiag_tile(int scheme, const SolveArgs& a, hipStream_t s, bool& done);
+int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s);
+__host__ __device__ inline int zqpa_M(int nz) { return nz < 100 ? nz : 100; }
 void host_quad_nodes(double mu_s, double* psi_nodes);
 
 }  // namespace crt

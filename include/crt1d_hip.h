@@ -11,6 +11,7 @@
  *   solve_bl   crt1d/solvers/_solve_bl.py:9-93       ->  crt_hip_bl_f64
  *   solve_g77  crt1d/solvers/_solve_g77.py:7-135     ->  crt_hip_g77_f64
  *   solve_bf   crt1d/solvers/_solve_bf.py:7-154      ->  crt_hip_bf_f64
+ *   solve_zq_pa crt1d/solvers/_solve_zq_pa.py:24-418 ->  crt_hip_zq_pa_f64
  *
  * which `Model.run` dispatches to at crt1d/model.py:305-310.  The reference has no FFI of
  * its own (pure Python); INTEGRATION.md shows the ctypes stub a maintainer would add.
@@ -59,7 +60,7 @@ enum crt_g_kind {
 
 enum crt_scheme {
   CRT_SCHEME_2S = 0, CRT_SCHEME_4S = 1, CRT_SCHEME_N79 = 2, CRT_SCHEME_ZQ = 3,
-  CRT_SCHEME_BL = 4, CRT_SCHEME_G77 = 5, CRT_SCHEME_BF = 6, CRT_NUM_SCHEMES = 7
+  CRT_SCHEME_BL = 4, CRT_SCHEME_G77 = 5, CRT_SCHEME_BF = 6, CRT_SCHEME_ZQ_PA = 7, CRT_NUM_SCHEMES = 8
 };
 
 enum crt_tau_d_method { CRT_TAU_D_QUAD = 0, CRT_TAU_D_9SKY = 1 }; /* _solve_n79.py:19, common.py:72-78 */
@@ -151,6 +152,10 @@ const char* crt_hip_strerror(int status);
 /* bytes of device workspace a solve of `scheme` needs for (ncol, nz) */
 size_t crt_hip_workspace_bytes(int scheme, int32_t ncol, int32_t nz);
 
+/* same, for schemes whose workspace also depends on the number of bands (zq_pa keeps its computational-grid fluxes
+ * there: 2 * ncol * min(100, nz) * nb doubles); equals crt_hip_workspace_bytes for every other scheme */
+size_t crt_hip_workspace_bytes_nb(int scheme, int32_t ncol, int32_t nz, int32_t nb);
+
 /* host: fill psi_nodes[CRT_NQ] with the zenith angles (radians) at which g_table is sampled */
 int crt_hip_quad_nodes(double mu_s, double* psi_nodes);
 
@@ -164,6 +169,7 @@ int crt_hip_zq_f64(const crt_columns*, const crt_bands*, const crt_options*, con
 int crt_hip_bl_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
 int crt_hip_g77_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
 int crt_hip_bf_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
+int crt_hip_zq_pa_f64(const crt_columns*, const crt_bands*, const crt_options*, const crt_outputs*, void*, size_t, crt_stream_t);
 
 int crt_hip_solve_f32(int scheme, const crt_columns* cols, const crt_bands_f32* bands, const crt_options* opts,
                       const crt_outputs_f32* out, void* workspace, size_t workspace_bytes, crt_stream_t stream);

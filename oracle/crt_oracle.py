@@ -507,6 +507,97 @@ def solve_zq(cols, *, I_dr0, I_df0, leaf_r, leaf_t, soil_r, exact_quad=False):
     }  # :201-229
 
 
+def solve_zq_pa(cols, *, I_dr0, I_df0, leaf_r, leaf_t, soil_r, clump=1.0, exact_quad=False):
+    """Zhao & Qualls, pyAPES variant; _solve_zq_pa.py:24-418 (scope row f, rank 3).
+
+    The canopy is regridded to M = min(100, N) equal layers (:94-100), the zq tridiagonal system is solved there
+    (:196-278) with tau_d(LAI/M) for every layer (:176), eqs. 24/25 give SWd, SWu on the M+1 interfaces (:286-335)
+    with the end values copied from their neighbours (:310,335), and the result is interpolated linearly in cumulative
+    LAI back to the original levels (:357-362).  `clump` and K_d only enter absorption terms the reference computes
+    but does not return (:364-404)."""
+    nc, N = cols.ncol, cols.nz
+    M = min(100, N)
+    Kb = cols.K_b()
+    mu = np.cos(cols.psi)
+    LAI = cols.lai[:, 0]
+    I_dr0a = _bc(I_dr0, nc)[:, 0, :]
+    I_df0a = _bc(I_df0, nc)[:, 0, :]
+    bL = _bc(leaf_r, nc)[:, 0, :]
+    tauL = _bc(leaf_t, nc)[:, 0, :]
+    rho = _bc(soil_r, nc)[:, 0, :]
+    nb = bL.shape[-1]
+    alb = bL + tauL
+    Lm = LAI / M
+    taud_i = tau_d(cols, Lm[:, None], exact_quad=exact_quad)[:, 0]  # :176
+    taub_i = np.exp(-Kb * Lm)  # :174
+
+    shp = (M + 2, nc, nb)
+    aL = np.broadcast_to(1 - alb, shp).copy()  # :141
+    tL = np.broadcast_to(tauL / alb, shp).copy()
+    rL = np.broadcast_to(bL / alb, shp).copy()
+    aL[0], tL[0], rL[0] = 1 - rho, 0, 1  # :148-150
+    aL[-1], tL[-1], rL[-1] = 0, 1, 0  # :153-155
+    L = np.full((M + 2, nc), 1.0) * Lm[None, :]
+    L[0] = 0
+    L[-1] = 0
+    Lcum = np.cumsum(L[::-1], axis=0)  # from the top: 0, Lm, ..., LAI, LAI   (:159)
+    f_sl = np.exp(-Kb[None, :] * Lcum)[::-1]  # :164
+    Ib = f_sl[:, :, None] * I_dr0a[None]  # :168
+    taub = np.broadcast_to(taub_i[None, :, None], shp).copy()
+    taud = np.broadcast_to(taud_i[None, :, None], shp).copy()
+    taub[0] = 0
+    taud[0] = 0  # :180-181
+    # note: taub/taud of the top ghost layer (L = 0) are exp(0) = 1 for taub but tau_d(LAI/M) for taud (:176 fills all)
+    taub[-1] = 1.0
+    rb = 0.5 + 0.3334 * (rL - tL) / (rL + tL) * mu[None, :, None]  # :186
+    rd = 2.0 / 3.0 * rL / (rL + tL) + 1.0 / 3.0 * tL / (rL + tL)  # :187
+    rb[0], rd[0], rb[-1], rd[-1] = 1, 1, 0, 0  # :189-192
+
+    n = 2 * M + 2
+    sub = np.zeros((n, nc, nb))
+    dia = np.zeros((n, nc, nb))
+    sup = np.zeros((n, nc, nb))
+    C = np.zeros((n, nc, nb))
+    k = np.arange(1, M + 1)
+    fwd = taud[k] + (1 - taud[k]) * (1 - aL[k]) * (1 - rd[k])
+    q = rd * (1 - aL) * (1 - taud)  # r (1-a) (1-t) per layer
+    dlo = 1 - q[k - 1] * q[k]
+    dhi = 1 - q[k] * q[k + 1]
+    dia[0] = 1  # :199
+    sub[2 * k - 1] = -fwd  # :207
+    dia[2 * k - 1] = -q[k - 1] * fwd  # :208-213
+    sup[2 * k - 1] = dlo  # :214-216
+    sub[2 * k] = dhi  # :218-220
+    dia[2 * k] = -q[k + 1] * fwd  # :221-226
+    sup[2 * k] = -fwd  # :227
+    dia[n - 1] = 1  # :230
+    C[0] = rho * Ib[0]  # :238
+    C[2 * k - 1] = dlo * rb[k] * (1 - taub[k]) * (1 - aL[k]) * Ib[k]  # :242-255
+    C[2 * k] = dhi * (1 - taub[k]) * (1 - aL[k]) * (1 - rb[k]) * Ib[k]  # :256-269
+    C[n - 1] = I_df0a  # :274
+    x = _thomas(sub, dia, sup, C)  # np.linalg.solve, :277
+    SWu0, SWd0 = x[0::2], x[1::2]
+    SWd = np.zeros((M + 1, nc, nb))
+    SWu = np.zeros((M + 1, nc, nb))
+    kk = np.arange(0, M)
+    den = 1 - q[kk] * q[kk + 1]
+    SWd[kk + 1] = SWd0[kk + 1] / den + SWu0[kk] * q[kk + 1] / den  # eq. 24 :286-309
+    SWd[0] = SWd[1]  # :310
+    SWu[kk] = SWu0[kk] / den + SWd0[kk + 1] * q[kk] / den  # eq. 25 :313-334
+    SWu[M] = SWu[M - 1]  # :335
+
+    dn = np.empty((nc, N, nb))
+    up = np.empty((nc, N, nb))
+    for c in range(nc):
+        xi = Lcum[: M + 1, c]  # 0 .. LAI ascending = cumulative LAI of interfaces M .. 0   (:338-341,359)
+        X = cols.lai[c][::-1]
+        for i in range(nb):
+            dn[c, :, i] = np.interp(X, xi, SWd[::-1, c, i])[::-1]  # :360
+            up[c, :, i] = np.interp(X, xi, SWu[::-1, c, i])[::-1]  # :361
+    I_dr = I_dr0a[:, None, :] * np.exp(-Kb[:, None] * cols.lai)[:, :, None]  # :354-355
+    return {"I_dr": I_dr, "I_df_d": dn, "I_df_u": up, "F": I_dr / mu[:, None, None] + 2 * up + 2 * dn}  # :406-418
+
+
 def _coef_4s(om, R_dr0, G1, G2, mu_s):
     """Tian (2007) eq. 4 coefficients with P = 1; _solve_4s.py:188-203."""
     mu_1 = 0.5 * mu_s**2
@@ -609,7 +700,7 @@ def solve_4s(cols, *, I_dr0, I_df0, leaf_r, leaf_t, soil_r, mu_s=0.501, method="
     return {"I_dr": I_dr, "I_df_d": dn, "I_df_u": up, "F": I_dr / mu0[:, None, None] + 2 * up + 2 * dn}
 
 
-SOLVERS = {"2s": solve_2s, "4s": solve_4s, "bf": solve_bf, "bl": solve_bl, "g77": solve_g77, "n79": solve_n79, "zq": solve_zq}
+SOLVERS = {"2s": solve_2s, "4s": solve_4s, "bf": solve_bf, "bl": solve_bl, "g77": solve_g77, "n79": solve_n79, "zq": solve_zq, "zq_pa": solve_zq_pa}
 
 
 # ----------------------------------------------------------------------------------------------

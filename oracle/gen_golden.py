@@ -268,9 +268,9 @@ def main():
     if want("g2"):
         g2(la, lar, sol, out)
     if want("g3"):
-        synth_case(la, sol, out, "g3_uniform", 12, 10, 60, True, ["2s", "4s", "bf", "bl", "g77", "n79", "zq"], True)
+        synth_case(la, sol, out, "g3_uniform", 12, 10, 60, True, ["2s", "4s", "bf", "bl", "g77", "n79", "zq", "zq_pa"], True)
     if want("g4"):
-        synth_case(la, sol, out, "g4_ragged", 12, 10, 40, False, ["2s", "4s", "bf", "bl", "g77", "n79", "zq"], True)
+        synth_case(la, sol, out, "g4_ragged", 12, 10, 40, False, ["2s", "4s", "bf", "bl", "g77", "n79", "zq", "zq_pa"], True)
     if want("g7"):
         g7(la, lar, sol, out)
 

@@ -7,7 +7,7 @@ from conftest import load_golden, rel_profile_err
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"2s": 1e-11, "g77": 1e-11, "bf": 1e-11, "bl": 1e-6, "n79": 1e-6, "zq": 1e-6}
+TOL = {"2s": 1e-11, "g77": 1e-11, "bf": 1e-11, "bl": 1e-6, "n79": 1e-6, "zq": 1e-6, "zq_pa": 1e-6}
 
 
 def _ref_style_kwargs(g):
@@ -17,11 +17,11 @@ def _ref_style_kwargs(g):
     G_fn = lambda psi_: np.sqrt(x**2 + np.tan(psi_) ** 2) / (x + 1.774 * (x + 1.182) ** -0.733) * np.cos(psi_)  # noqa: E731
     return dict(
         psi=float(g["psi"]), I_dr0_all=g["I_dr0_all"], I_df0_all=g["I_df0_all"], lai=g["lai"], leaf_t=g["leaf_t"], leaf_r=g["leaf_r"],
-        soil_r=g["soil_r"], K_b_fn=lambda psi_: G_fn(psi_) / np.cos(psi_), G_fn=G_fn, mla=float(g["mla"]),
+        soil_r=g["soil_r"], K_b_fn=lambda psi_: G_fn(psi_) / np.cos(psi_), G_fn=G_fn, mla=float(g["mla"]), clump=1.0,
     )
 
 
-@pytest.mark.parametrize("scheme", ["2s", "4s", "n79", "zq", "bl", "g77", "bf"])
+@pytest.mark.parametrize("scheme", ["2s", "4s", "n79", "zq", "bl", "g77", "bf", "zq_pa"])
 def test_plugin_functions_with_plain_callables(scheme):
     from crt1d_amd import solvers
 
@@ -46,7 +46,7 @@ def test_plugin_functions_with_plain_callables(scheme):
             assert rel_profile_err(v, g[f"{scheme}__{k}"]) <= TOL[scheme], k
 
 
-@pytest.mark.parametrize("scheme", ["2s", "4s", "n79", "zq", "bl", "g77", "bf"])
+@pytest.mark.parametrize("scheme", ["2s", "4s", "n79", "zq", "bl", "g77", "bf", "zq_pa"])
 def test_model_run_default_case(scheme):
     """Model(scheme).run() on the default canopy (BASELINE config 1: 1 profile x 107 bands x 60 levels)."""
     from crt1d_amd.model import Model

@@ -19,6 +19,8 @@ def test_registry_matches_reference_introspection():
         "g77": (common + ["soil_r", "K_b_fn"], [], "G77", "Goudriaan (1977)"),
         "n79": (common + ["soil_r", "K_b_fn"], ["tau_d_method"], "N79", "Norman (1979)"),
         "zq": (common + ["soil_r", "K_b_fn", "G_fn"], [], "ZQ", "Zhao & Qualls multi-scattering"),
+        "zq_pa": (["psi", "I_dr0_all", "I_df0_all", "lai", "clump", "leaf_t", "leaf_r", "soil_r", "K_b_fn"], [], "ZQ-pA",
+                  "Zhao & Qualls multi-scattering (pyAPES)"),
     }
     assert sorted(solvers.AVAILABLE_SCHEMES) == sorted(expect)
     for k, (args, opts, sn, ln) in expect.items():

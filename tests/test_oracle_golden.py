@@ -29,7 +29,7 @@ def _kw(g, scheme, sl=slice(None)):
     return kw
 
 
-@pytest.mark.parametrize("scheme,tol", [("2s", 1e-11), ("g77", 1e-12), ("bf", 1e-12), ("bl", 1e-6), ("n79", 1e-8), ("zq", 1e-8)])
+@pytest.mark.parametrize("scheme,tol", [("2s", 1e-11), ("g77", 1e-12), ("bf", 1e-12), ("bl", 1e-6), ("n79", 1e-8), ("zq", 1e-8), ("zq_pa", 1e-8)])
 def test_default_case(oracle, scheme, tol):
     g = load_golden("g1_default")
     res = oracle.SOLVERS[scheme](_cols(oracle, g), **_kw(g, scheme))
@@ -40,7 +40,7 @@ def test_default_case(oracle, scheme, tol):
         assert rel_profile_err(v[0], g[f"{scheme}__{k}"]) <= tol, k
 
 
-@pytest.mark.parametrize("scheme", ["2s", "bl", "n79", "zq"])
+@pytest.mark.parametrize("scheme", ["2s", "bl", "n79", "zq", "zq_pa"])
 def test_default_case_exact_quad(oracle, scheme):
     """With the reference's own QUADPACK calls the restatement agrees with the reference to rounding."""
     g = load_golden("g1_default")
@@ -82,12 +82,12 @@ def test_bonan_n79(oracle):
 
 
 @pytest.mark.parametrize("name", ["g3_uniform", "g4_ragged"])
-@pytest.mark.parametrize("scheme", ["2s", "4s", "bf", "bl", "g77", "n79", "zq"])
+@pytest.mark.parametrize("scheme", ["2s", "4s", "bf", "bl", "g77", "n79", "zq", "zq_pa"])
 def test_synthetic(oracle, name, scheme):
     g = load_golden(name)
     res = oracle.SOLVERS[scheme](_cols(oracle, g), **_kw(g, scheme))
     pre = "4s_tol1e-11" if scheme == "4s" else scheme
-    tol = {"2s": 1e-10, "g77": 1e-12, "bf": 1e-12, "4s": 1e-9, "bl": 1e-6, "zq": 1e-6, "n79": 1e-6}[scheme]
+    tol = {"2s": 1e-10, "g77": 1e-12, "bf": 1e-12, "4s": 1e-9, "bl": 1e-6, "zq": 1e-6, "n79": 1e-6, "zq_pa": 1e-6}[scheme]
     for k, v in res.items():
         if k == "rho_c":
             continue
