@@ -208,3 +208,30 @@ def test_f32_storage_variant(scheme, shape):
         assert torch.equal(s32[k], s64[k].float()), k
     with pytest.raises(TypeError):
         batched.Bands(b32.I_dr0, b64.I_df0, b32.leaf_r, b32.leaf_t, b32.soil_r)
+
+
+@pytest.mark.parametrize("scheme", ["2s", "n79"])
+def test_dist_paths_on_the_hip_kernels(oracle, scheme):
+    """crt1d_amd.dist with its default (HIP) compute functions, world size 1: both partitions give the same integrated
+    results, equal to the oracle's.  (The multi-rank packing / all-reduce logic is covered by tests/test_dist_gloo.py.)"""
+    import torch
+
+    from crt1d_amd import batched, spectra, synth
+    from crt1d_amd.dist import solve_sharded
+
+    d = synth.make_columns(23, 300, 60, seed=12)
+    cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
+    w = torch.as_tensor(spectra.band_weights(d["wle"])).cuda()
+    rc = solve_sharded(scheme, cols, bands, w, partition="column")
+    rb = solve_sharded(scheme, cols, bands, w, partition="band")
+    assert rc["columns"] == (0, 23) and rb["columns"] == (0, 23)
+    for k in ("aI", "aI_sl", "aI_sh", "totals", "reflectance"):
+        assert torch.equal(rc[k], rb[k]), k
+    oc = oracle.Columns(d["psi"], d["lai"], mla=d["mla"], g_kind=d["g_kind"], g_param=d["g_param"])
+    kw = dict(I_dr0=d["I_dr0"], I_df0=d["I_df0"], leaf_r=d["leaf_r"], leaf_t=d["leaf_t"], soil_r=d["soil_r"])
+    ref = oracle.SOLVERS[scheme](oc, **kw)
+    ab = oracle.calc_absorption(oc, ref, leaf_r=d["leaf_r"], leaf_t=d["leaf_t"])
+    wn = w.cpu().numpy()
+    np.testing.assert_allclose(rc["aI"].cpu().numpy(), ab["aI"] @ wn.T, rtol=1e-9, atol=1e-12)
+    refl = (ref["I_df_u"][:, -1] @ wn.T) / ((ref["I_dr"][:, -1] + ref["I_df_d"][:, -1]) @ wn.T)
+    np.testing.assert_allclose(rc["reflectance"].cpu().numpy(), refl, rtol=1e-9)
