@@ -510,7 +510,7 @@ struct TileCfg {
 // the tile protocol only needs the LDS writes/reads of the other waves to have completed.
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <class S, typename TIO, int MAXT>
+template <class S, typename TIO, int MAXT, bool FUSED>
 __global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {
   constexpr int VW = 16 / (int)sizeof(TIO);  // elements per 16-B store: 2 doubles / 4 floats
   typedef TIO vt __attribute__((ext_vector_type(VW)));
@@ -533,6 +533,14 @@ __global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {
   S st;
   if (active) st.init(rec, load_band<TIO>(a, c0 + cl, b, S::SOIL), a);
   const int colrun = T * nb;  // elements per (array, column) slot of the tile
+  // FUSED flush (one column per workgroup, nb a multiple of the 16-B vector width, 16-B aligned outputs): a vector never
+  // straddles a row, so thread -> (row offset, vector within the row) is fixed for the whole kernel and all NARR arrays
+  // are flushed in one pass with no per-array address set-up.  Rows of a tile are adjacent in memory, so consecutive
+  // threads still write consecutive 16-B words (a wave store = 1 KiB, line aligned).
+  const int nbv = nb / VW;
+  const int f_toff = FUSED ? tid / nbv : 0;
+  const int f_p = FUSED ? tid - f_toff * nbv : 0;
+  const int f_rpi = FUSED ? nthr / nbv : 1;
 
   for (int j0 = 0; j0 < nz; j0 += T) {
     const int Tc = min(T, nz - j0);
@@ -546,6 +554,19 @@ __global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {
       }
     }
     if (cfg.flags & 1) __syncthreads(); else lds_barrier();
+    if constexpr (FUSED) {
+      if (f_toff < f_rpi) {
+        const vt* tv = reinterpret_cast<const vt*>(tile);
+        for (int t = f_toff; t < Tc; t += f_rpi) {
+          const long long go = ((long long)c0 * nz + j0 + t) * nbv + f_p;
+          vt v[S::NARR];
+#pragma unroll
+          for (int k = 0; k < S::NARR; ++k) v[k] = tv[(k * colrun + t * nb) / VW + f_p];
+#pragma unroll
+          for (int k = 0; k < S::NARR; ++k) reinterpret_cast<vt*>(a.o[k])[go] = v[k];
+        }
+      }
+    } else {
     // flush: per (array, column) one contiguous run of Tc * nb elements
     const int n = Tc * nb;
     for (int k = 0; k < S::NARR; ++k) {
@@ -573,6 +594,7 @@ __global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {
         if (tid < tail) g[mis + nvec * VW + tid] = s[mis + nvec * VW + tid];
       }
     }
+    }
     if (cfg.flags & 1) __syncthreads(); else lds_barrier();
   }
 }
@@ -580,7 +602,7 @@ __global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_DIRECT_LDS = 64 * 1024;
 // tunables (crt_hip_tune): [0] LDS bytes a tile may take per workgroup, [1] force T (0 = automatic),
-// [2] TileCfg.flags.  Measured on MI355X, 2s at 1e4 x 300 x 60 (tools/ab_tile.py, interleaved rounds):
+// [2] TileCfg.flags (bit0: __syncthreads barriers, bit1: generic instead of fused flush).  Measured on MI355X, 2s at 1e4 x 300 x 60 (tools/ab_tile.py, interleaved rounds):
 //   T=2 (not line aligned) 1.66 ms | T=4, 4 WG/CU 1.20 ms | T=8, 2 WG/CU 1.03 ms | T=12, 1 WG/CU 1.25 ms
 // -> take the longest line-aligned run that still leaves two workgroups resident per CU (160 KB LDS).
 int g_tune[8] = {78 * 1024, 0, 0, 0, 0, 0, 0, 0};
@@ -615,20 +637,30 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
   cfg.flags = g_tune[2];
   const size_t sh = cfg.rec_dbl * sizeof(double) + (size_t)S::NARR * CB * T * nb * sizeof(TIO);
   if (sh > 160 * 1024) return CRT_OK;
-  if (sh > 64 * 1024) {
-    const void* fn = nthr <= 256 ? (const void*)k_tile<S, TIO, 256> : nthr <= 512 ? (const void*)k_tile<S, TIO, 512>
-                                                                                   : (const void*)k_tile<S, TIO, 1024>;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return CRT_ERR_LAUNCH;
-  }
+  constexpr int VW = 16 / (int)sizeof(TIO);
+  bool fused = CB == 1 && nb % VW == 0 && !(g_tune[2] & 2);
+  for (int i = 0; i < S::NARR && fused; ++i)
+    if (reinterpret_cast<uintptr_t>(a.o[i]) & 15) fused = false;
   const int grid = (a.ncol + CB - 1) / CB;
-  if (nthr <= 256)
-    hipLaunchKernelGGL((k_tile<S, TIO, 256>), dim3(grid), dim3(nthr), sh, s, a, cfg);
-  else if (nthr <= 512)
-    hipLaunchKernelGGL((k_tile<S, TIO, 512>), dim3(grid), dim3(nthr), sh, s, a, cfg);
-  else
-    hipLaunchKernelGGL((k_tile<S, TIO, 1024>), dim3(grid), dim3(nthr), sh, s, a, cfg);
-  done = true;
-  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+  auto go = [&](auto kern) {
+    if (sh > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+      return (int)CRT_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nthr), sh, s, a, cfg);
+    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+  };
+  int st;
+  if (fused) {
+    if (nthr <= 256) st = go(k_tile<S, TIO, 256, true>);
+    else if (nthr <= 512) st = go(k_tile<S, TIO, 512, true>);
+    else st = go(k_tile<S, TIO, 1024, true>);
+  } else {
+    if (nthr <= 256) st = go(k_tile<S, TIO, 256, false>);
+    else if (nthr <= 512) st = go(k_tile<S, TIO, 512, false>);
+    else st = go(k_tile<S, TIO, 1024, false>);
+  }
+  done = st == CRT_OK;
+  return st;
 }
 
 template <class S, typename TIO, int VEC, bool USE_LDS>

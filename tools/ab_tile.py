@@ -11,11 +11,12 @@ cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
 plan = batched.Plan(scheme, cols, bands)
 lib = _lib.load()
 variants = {
-    "tile T=4 ldsbar": {0: 40960, 1: 4, 2: 0},
-    "tile T=4 syncthreads": {0: 40960, 1: 4, 2: 1},
-    "tile T=8 ldsbar": {0: 160 * 1024, 1: 8, 2: 0},
-    "tile T=12 ldsbar": {0: 160 * 1024, 1: 12, 2: 0},
-    "tile T=2 ldsbar": {0: 40960, 1: 2, 2: 0},
+    "tile T=8 fused": {0: 160 * 1024, 1: 8, 2: 0},
+    "tile T=8 generic flush": {0: 160 * 1024, 1: 8, 2: 2},
+    "tile T=4 fused": {0: 40960, 1: 4, 2: 0},
+    "tile T=4 generic flush": {0: 40960, 1: 4, 2: 2},
+    "tile T=12 fused": {0: 160 * 1024, 1: 12, 2: 0},
+    "tile T=16 fused": {0: 160 * 1024, 1: 16, 2: 0},
     "direct": None,
 }
 res = {k: [] for k in variants}
