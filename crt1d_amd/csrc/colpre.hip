@@ -306,6 +306,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
         v[3 * nz + j] = fs;
         v[4 * nz + j] = isl;
         v[5 * nz + j] = ish;
+        v[6 * nz + j] = 1.0 / (1.0 - td);  // refld = (1 - td) rho  ->  1/refld = (1/rho) * this
         break;
       }
       default:  // 2s, 4s, g77, bf

@@ -15,7 +15,7 @@ namespace crt {
 //   vectors (by scheme):
 //     2s, 4s, g77, bf : lai, ekl = exp(-K_b lai)
 //     bl              : lai, ekl, tau_d(lai_j)                       (_solve_bl.py:31-37)
-//     n79             : tbcum = ekl, tb, td, fracsun, 1/(fracsun dlai), 1/(fracsha dlai)
+//     n79             : tbcum = ekl, tb, td, fracsun, 1/(fracsun dlai), 1/(fracsha dlai), 1/(1 - td)
 //                                                                     (_solve_n79.py:40-59)
 //     zq              : ekl                                           (_solve_zq.py:130)
 //     zq_pa           : beam fraction on the M computational layers, ekl, interpolation index, weight
@@ -42,7 +42,7 @@ enum RecScalar {
 __host__ __device__ inline int rec_nvec(int scheme) {
   switch (scheme) {
     case CRT_SCHEME_BL: return 3;
-    case CRT_SCHEME_N79: return 6;
+    case CRT_SCHEME_N79: return 7;
     case CRT_SCHEME_ZQ_PA: return 4;
     case CRT_SCHEME_ZQ: return 1;
     default: return 2;

@@ -1,0 +1,227 @@
+// Scheme objects of the tridiagonal solvers (n79, zq), shared by the column-tile kernel (solve_tridiag_tile.hip) and the
+// per-wave fallback kernels (solve_tridiag.hip) so that both produce identical bits.  Not part of the ABI.
+#pragma once
+#include "crt_internal.hpp"
+
+namespace crt {
+namespace {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// n79 (crt1d/solvers/_solve_n79.py:70-155).  Even row k <-> upward flux at level k, k = 0 .. nz-1.
+struct TriN79 {
+  static constexpr int NST = 4;   // staged: dn, up, aI_lsl, aI_lsh
+  static constexpr int NOUT = 6;  // I_dr, I_df_d, I_df_u, F, aI_lsl, aI_lsh
+  double swb, swd, rho, tau, alb, oma, invmu, irho;
+  double dn, up;  // back-substitution state (level k+1)
+
+  __host__ __device__ static inline int rows(int nz) { return nz; }               // even rows
+  __host__ __device__ static inline int out_rows(int arr, int nz) { return arr >= 4 ? nz - 1 : nz; }
+  __device__ inline double band_const() const { return swb; }
+
+  template <typename TIO>
+  __device__ inline void init(const double* rec, const SolveArgs& a, int c, int b) {
+    const long long i = (long long)c * a.col_stride + b;
+    swb = ldio<TIO>(a.I_dr0, i);
+    swd = ldio<TIO>(a.I_df0, i);
+    rho = ldio<TIO>(a.leaf_r, i);
+    tau = ldio<TIO>(a.leaf_t, i);
+    alb = ldio<TIO>(a.soil_r, i);
+    oma = 1 - (rho + tau);  // :56,145
+    irho = fast_rcp(rho);
+    invmu = rec[S_INVMU];
+  }
+  // layer scattering coefficients (:85-88 / :102-105): r = trand/refld, s = refld - trand^2/refld.
+  // 1/refld = (1/rho) * 1/(1 - td_j): a per-band register times a per-level K0 vector, no division here.
+  __device__ inline void layer(const double* rec, int nz, int j, double& r, double& s) const {
+    const double t = rec[REC_HDR + 2 * nz + j];
+    const double refld = (1 - t) * rho;
+    const double trand = (1 - t) * tau + t;
+    r = trand * (irho * rec[REC_HDR + 6 * nz + j]);
+    s = refld - trand * r;
+  }
+  __device__ inline void first(const double* rec, int nz, double& e, double& f) const {
+    e = -alb;  // row 0: soil, upward (:79-82)
+    f = swb * rec[REC_HDR] * alb;
+  }
+  // even pair of level k -> even pair of level k+1: the odd row of level k (layer m) and the even row of level k+1
+  // (layer k) of the Thomas sweep (:180-192 applied to rows :85-129), merged into one rational update so that a
+  // single reciprocal is needed:   A = 1 + s_m e,  D = A - r_k r_m,
+  //   e' = -s_k A / D,   f' = (d_even A + r_k (d_odd + s_m f)) / D.     (|r r| >> |A|: no cancellation in D)
+  __device__ inline void advance(int k, const double* rec, int nz, double& e, double& f) const {
+    const double* tbcum = rec + REC_HDR;
+    const double* tb = tbcum + nz;
+    const int mk = k == 0 ? 1 : k;  // the first downward row uses layer index 1 (:85-92), as the reference
+    double rm, sm, r, s;
+    layer(rec, nz, mk, rm, sm);
+    if (k == 0) {
+      layer(rec, nz, 0, r, s);
+    } else {
+      r = rm;
+      s = sm;
+    }
+    const double src = swb * tbcum[k + 1];
+    const double d_odd = src * (1 - tb[mk]) * (tau - rho * rm);   // (:92, :119)
+    const double d_even = src * (1 - tb[k]) * (rho - tau * r);    // (:109, :129)
+    const double A = 1 + sm * e;
+    const double iD = fast_rcp(A - r * rm);
+    e = -s * A * iD;
+    f = (d_even * A + r * (d_odd + sm * f)) * iD;
+  }
+  // top even row (k = nz-1): dn = sky diffuse (:132-135); emits output level nz-1 (no layer above it)
+  __device__ inline void top(const double* rec, int nz, double e, double f, double (&o)[NST]) {
+    dn = swd;
+    up = f - e * dn;
+    o[0] = dn;
+    o[1] = up;
+    o[2] = 0.0;
+    o[3] = 0.0;
+  }
+  // level k from level k+1; emits output level k and layer k
+  __device__ inline void back(int k, const double* rec, int nz, double e, double f, double (&o)[NST]) {
+    const double* tbcum = rec + REC_HDR;
+    const double* tb = tbcum + nz;
+    const double t = rec[REC_HDR + 2 * nz + k];
+    const double refld = (1 - t) * rho;
+    const double trand = (1 - t) * tau + t;
+    const double src = swb * tbcum[k + 1] * (1 - tb[k]);
+    const double dn1 = dn;
+    // dn_k from the upward equation of level k+1 (layer k):  -r dn_k + up_{k+1} - s dn_{k+1} = d
+    dn = (refld * up + (trand * trand - refld * refld) * dn1 - src * (rho * refld - tau * trand)) * fast_rcp(trand);
+    up = f - e * dn;
+    const double direct = src * oma;                       // :145
+    const double diffuse = (dn1 + up) * (1 - t) * oma;     // :146
+    const double fs = rec[REC_HDR + 3 * nz + k];
+    o[0] = dn;
+    o[1] = up;
+    o[2] = (diffuse * fs + direct) * rec[REC_HDR + 4 * nz + k];  // :154
+    o[3] = (diffuse * (1 - fs)) * rec[REC_HDR + 5 * nz + k];     // :155
+  }
+  // value of output array `arr` at tile row t (level j), band b; st[] = staged arrays at that element
+  template <int ARR>
+  __device__ static inline double value(const double* rec, int nz, int j, double bc, double invmu_, const double* tile, int stride,
+                                        int idx) {
+    if constexpr (ARR == 0) return bc * rec[REC_HDR + j];                                                          // :151
+    if constexpr (ARR == 1) return tile[idx];
+    if constexpr (ARR == 2) return tile[stride + idx];
+    if constexpr (ARR == 3) return bc * rec[REC_HDR + j] * invmu_ + 2 * tile[idx] + 2 * tile[stride + idx];        // :161
+    if constexpr (ARR == 4) return tile[2 * stride + idx];
+    return tile[3 * stride + idx];
+  }
+  static constexpr bool derived(int arr) { return arr == 0 || arr == 3; }
+  static constexpr int staged_slot(int arr) { return arr == 1 ? 0 : arr == 2 ? 1 : arr == 4 ? 2 : 3; }
+  // all outputs of one (level j, band pair) from the staged pairs st[]; same expressions as value<>()
+  __device__ static inline void emit(const double* rec, int nz, int j, d2 bc, double invmu_, const d2 (&st)[NST], d2 (&o)[NOUT]) {
+    const d2 idr = bc * rec[REC_HDR + j];
+    o[0] = idr;
+    o[1] = st[0];
+    o[2] = st[1];
+    o[3] = idr * invmu_ + 2 * st[0] + 2 * st[1];
+    o[4] = st[2];
+    o[5] = st[3];
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// zq (crt1d/solvers/_solve_zq.py:74-219).  Even row k <-> SWu0[k], k = 0 .. m (m = nz); output level z = k, k < m.
+struct TriZq {
+  static constexpr int NST = 4;   // staged: I_df_d, I_df_u, I_df_d_ss, I_df_u_ss
+  static constexpr int NOUT = 7;  // I_dr, I_df_d, I_df_u, F, I_df_d_ss, I_df_u_ss, F_ss
+  double I_dr0, I_df0, rho, fwd, q, q0, cu, cd, invmu;
+  double xd, xu;  // SWd0[li], SWu0[li] of the level above
+
+  __host__ __device__ static inline int rows(int nz) { return nz + 1; }
+  __host__ __device__ static inline int out_rows(int, int nz) { return nz; }
+  __device__ inline double band_const() const { return I_dr0; }
+
+  template <typename TIO>
+  __device__ inline void init(const double* rec, const SolveArgs& a, int c, int b) {
+    const long long i = (long long)c * a.col_stride + b;
+    I_dr0 = ldio<TIO>(a.I_dr0, i);
+    I_df0 = ldio<TIO>(a.I_df0, i);
+    const double bL = ldio<TIO>(a.leaf_r, i), tL = ldio<TIO>(a.leaf_t, i);
+    rho = ldio<TIO>(a.soil_r, i);
+    const double mu = rec[S_MU], t = rec[S_TAUI], t_psi = rec[S_TPSI];
+    invmu = rec[S_INVMU];
+    const double aL = 1 - (bL + tL);                                             // :87
+    const double r_i = 2.0 / 3 * (bL / (bL + tL)) + 1.0 / 3 * (tL / (bL + tL));  // eq. 23 :40-43
+    const double r_psi = 0.5 + 0.3334 * ((bL - tL) / (bL + tL)) * mu;            // eq. 22 :35-38
+    fwd = t + (1 - t) * (1 - aL) * (1 - r_i);                                    // :116
+    q = r_i * (1 - aL) * (1 - t);
+    q0 = 1.0 * (1 - (1 - rho)) * (1 - 0.0);  // ground "layer": r=1, t=0, a=1-rho (:106-108)
+    cu = r_psi * (1 - t_psi) * (1 - aL);        // :139
+    cd = (1 - t_psi) * (1 - aL) * (1 - r_psi);  // :142
+  }
+  __device__ inline void first(const double* rec, int nz, double& e, double& f) const {
+    e = 0.0;  // row 0: x0 = rho S_0 (:115,136)
+    f = rho * (I_dr0 * rec[REC_HDR]);
+  }
+  // even pair of li-1 -> even pair of li: rows 2li-1 (sub -fwd, dia -qlo fwd, sup dlo; :116-118, rhs :137-139) and
+  // 2li (sub dhi, dia -qhi fwd, sup -fwd; :119-121, rhs :140-142) of the sweep, merged into one rational update:
+  //   B = fwd (e - qlo),  D = qhi fwd B + dhi dlo,   e' = fwd B / D,   f' = (dhi (C1 + fwd f) - C2 B) / D
+  __device__ inline void advance(int k, const double* rec, int m, double& e, double& f) const {
+    const int li = k + 1;
+    const double S = I_dr0 * rec[REC_HDR + li - 1];  // :130
+    const double qlo = (li == 1) ? q0 : q;
+    const double qhi = (li == m) ? 0.0 : q;
+    const double dlo = 1 - qlo * q;  // :118
+    const double dhi = 1 - q * qhi;  // :119
+    const double C1 = dlo * cu * S;
+    const double C2 = dhi * cd * S;
+    const double B = fwd * (e - qlo);
+    const double iD = fast_rcp(qhi * fwd * B + dhi * dlo);
+    e = fwd * B * iD;
+    f = (dhi * (C1 + fwd * f) - C2 * B) * iD;
+  }
+  // k = m: x[2m+1] = I_df0 (:122,143); no output row at k = m
+  __device__ inline void top(const double* rec, int m, double e, double f, double (&o)[NST]) {
+    xd = I_df0;
+    xu = f - e * xd;
+    o[0] = o[1] = o[2] = o[3] = 0.0;
+  }
+  __device__ inline void back(int k, const double* rec, int m, double e, double f, double (&o)[NST]) {
+    const int li = k + 1;
+    const double S = I_dr0 * rec[REC_HDR + k];
+    const double qlo = (li == 1) ? q0 : q;
+    const double qhi = (li == m) ? 0.0 : q;
+    const double dhi = 1 - q * qhi;
+    const double dlo = 1 - qlo * q;
+    // SWd0[li-1] from the original row 2li:  dhi x_{2li-1} - qhi fwd x_{2li} - fwd x_{2li+1} = C
+    const double xdl = (dhi * cd * S + qhi * fwd * xu + fwd * xd) * fast_rcp(dhi);
+    const double xul = f - e * xdl;  // SWu0[li-1]
+    const double iden = fast_rcp(dlo);   // multiple-scattering correction, eqs. 24/25 (:180-187)
+    o[0] = (xd + q * xul) * iden;
+    o[1] = (xul + qlo * xd) * iden;
+    o[2] = xd;   // I_df_d_ss :197
+    o[3] = xul;  // I_df_u_ss :199
+    xd = xdl;
+    xu = xul;
+  }
+  template <int ARR>
+  __device__ static inline double value(const double* rec, int nz, int j, double bc, double invmu_, const double* tile, int stride,
+                                        int idx) {
+    if constexpr (ARR == 0) return bc * rec[REC_HDR + j];                                                              // :219
+    if constexpr (ARR == 1) return tile[idx];
+    if constexpr (ARR == 2) return tile[stride + idx];
+    if constexpr (ARR == 3) return bc * rec[REC_HDR + j] * invmu_ + 2 * tile[stride + idx] + 2 * tile[idx];            // :202
+    if constexpr (ARR == 4) return tile[2 * stride + idx];
+    if constexpr (ARR == 5) return tile[3 * stride + idx];
+    return bc * rec[REC_HDR + j] * invmu_ + 2 * tile[3 * stride + idx] + 2 * tile[2 * stride + idx];                   // :201
+  }
+  static constexpr bool derived(int arr) { return arr == 0 || arr == 3 || arr == 6; }
+  static constexpr int staged_slot(int arr) { return arr == 1 ? 0 : arr == 2 ? 1 : arr == 4 ? 2 : 3; }
+  __device__ static inline void emit(const double* rec, int nz, int j, d2 bc, double invmu_, const d2 (&st)[NST], d2 (&o)[NOUT]) {
+    const d2 S = bc * rec[REC_HDR + j];
+    o[0] = S;
+    o[1] = st[0];
+    o[2] = st[1];
+    o[3] = S * invmu_ + 2 * st[1] + 2 * st[0];
+    o[4] = st[2];
+    o[5] = st[3];
+    o[6] = S * invmu_ + 2 * st[3] + 2 * st[2];
+  }
+};
+
+}  // namespace
+}  // namespace crt

@@ -52,7 +52,7 @@ def test_host_only_entry_points(lib):
     assert _lib.strerror(0) == "ok" and "workspace" in _lib.strerror(_lib.CRT_ERR_WORKSPACE)
     # record = 16-double header + nvec * nz
     assert lib.crt_hip_workspace_bytes(_lib.SCHEME_IDS["2s"], 10, 60) == 10 * (16 + 2 * 60) * 8
-    assert lib.crt_hip_workspace_bytes(_lib.SCHEME_IDS["n79"], 10, 60) == 10 * (16 + 6 * 60) * 8
+    assert lib.crt_hip_workspace_bytes(_lib.SCHEME_IDS["n79"], 10, 60) == 10 * (16 + 7 * 60) * 8
     assert lib.crt_hip_workspace_bytes(99, 10, 60) == 0
     nodes = _lib.quad_nodes(0.501)
     assert nodes.shape == (_lib.NQ,)
