@@ -89,6 +89,7 @@ EXPORTS = [
     "crt_hip_g77_f32",
     "crt_hip_bf_f32",
     "crt_hip_absorb_bandsum_f64",
+    "crt_hip_integrated_f64",
     "crt_hip_absorb_f64",
     "crt_hip_tune",
     "crt_hip_probe_fill_f64",
@@ -149,6 +150,11 @@ def load():
     lib.crt_hip_absorb_bandsum_f64.restype = ctypes.c_int
     lib.crt_hip_absorb_bandsum_f64.argtypes = [
         ctypes.POINTER(CrtColumns), ctypes.POINTER(CrtBands), _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp,
+    ]
+    lib.crt_hip_integrated_f64.restype = ctypes.c_int
+    lib.crt_hip_integrated_f64.argtypes = [
+        ctypes.c_int, ctypes.POINTER(CrtColumns), ctypes.POINTER(CrtBands), ctypes.POINTER(CrtOptions), _vp, ctypes.c_int32,
+        _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp,
     ]
     lib.crt_hip_absorb_f64.restype = ctypes.c_int
     lib.crt_hip_absorb_f64.argtypes = [ctypes.POINTER(CrtColumns), ctypes.POINTER(CrtBands), _vp, _vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp]

@@ -307,3 +307,47 @@ def absorb(cols: Columns, bands: Bands, sol):
     out["laim"] = laim
     out["f_slm"] = f_slm
     return out
+
+
+class IntegratedPlan:
+    """Fused solve + absorption + band integrals (``crt_hip_integrated_f64``): no profile ever reaches HBM.
+    Outputs as :func:`absorb_bandsum`: ``aI, aI_sl, aI_sh (ncol, nz-1, ngroup)``, ``totals (ncol, ngroup, 4)``."""
+
+    def __init__(self, scheme, cols: Columns, bands: Bands, band_w, *, mu_s=0.501, tau_d_method="quad", workspace=None):
+        if scheme not in _lib.SCHEME_IDS or scheme == "zq_pa":
+            raise ValueError(f"scheme {scheme!r} has no integrated kernel")
+        if tau_d_method not in _lib.TAU_D_METHODS:
+            raise ValueError("invalid `method`. Valid options are 'quad' and '9sky'.")
+        if bands.dtype != torch.float64:
+            raise TypeError("the integrated path takes float64 spectra")
+        self.lib = _lib.load()
+        self.scheme, self.cols, self.bands = scheme, cols, bands
+        band_w = _f64(band_w, "band_w")
+        if band_w.ndim == 1:
+            band_w = band_w[None, :]
+        if band_w.shape[1] != bands.nb or not 1 <= band_w.shape[0] <= 4:
+            raise ValueError("band_w must be (ngroup <= 4, nb)")
+        self.band_w = band_w
+        ncol, nz, ng, dev = cols.ncol, cols.nz, band_w.shape[0], cols.device
+        self.out = {k: torch.empty((ncol, nz - 1, ng), dtype=torch.float64, device=dev) for k in ("aI", "aI_sl", "aI_sh")}
+        self.out["totals"] = torch.empty((ncol, ng, 4), dtype=torch.float64, device=dev)
+        need = workspace_bytes(scheme, ncol, nz, bands.nb)
+        self.workspace = torch.empty(need, dtype=torch.uint8, device=dev) if workspace is None else workspace
+        self._c, self._b = cols.c_struct(), bands.c_struct(ncol)
+        self._o = _lib.CrtOptions(float(mu_s), _lib.TAU_D_METHODS[tau_d_method], 0)
+
+    def __call__(self, stream=None, *, flags=0):
+        s = torch.cuda.current_stream(self.cols.device) if stream is None else stream
+        self._o.flags = int(flags)
+        o = self.out
+        st = self.lib.crt_hip_integrated_f64(
+            _lib.SCHEME_IDS[self.scheme], ctypes.byref(self._c), ctypes.byref(self._b), ctypes.byref(self._o), self.band_w.data_ptr(),
+            self.band_w.shape[0], o["aI"].data_ptr(), o["aI_sl"].data_ptr(), o["aI_sh"].data_ptr(), o["totals"].data_ptr(),
+            self.workspace.data_ptr(), self.workspace.numel(), s.cuda_stream)
+        _lib.check(st, "crt_hip_integrated_f64")
+        return self.out
+
+
+def solve_integrated(scheme, cols: Columns, bands: Bands, band_w, **kw):
+    with torch.cuda.device(cols.device):
+        return IntegratedPlan(scheme, cols, bands, band_w, **kw)()

@@ -237,7 +237,8 @@ int crt_hip_quad_nodes(double mu_s, double* psi_nodes) {
 }
 
 static int solve_impl(int scheme, const crt_columns* cols, const crt_bands* bands, const crt_options* opts,
-                      const crt_outputs* out, void* workspace, size_t workspace_bytes, crt_stream_t stream, int f32) {
+                      const crt_outputs* out, void* workspace, size_t workspace_bytes, crt_stream_t stream, int f32,
+                      const IntArgs* integ = nullptr) {
   if (!scheme_ok(scheme) || !cols || !bands || !out) return CRT_ERR_BAD_ARG;
   const int ncol = cols->ncol, nz = cols->nz, nb = bands->nb;
   if (ncol <= 0 || nz <= 0 || nb <= 0) return CRT_ERR_BAD_ARG;
@@ -246,12 +247,14 @@ static int solve_impl(int scheme, const crt_columns* cols, const crt_bands* band
   if (!bands->I_dr0 || !bands->I_df0 || !bands->leaf_r || !bands->leaf_t) return CRT_ERR_BAD_ARG;
   if (scheme != CRT_SCHEME_BL && !bands->soil_r) return CRT_ERR_BAD_ARG;
   if (bands->col_stride != 0 && bands->col_stride < nb) return CRT_ERR_BAD_ARG;
-  if (!out->I_dr || !out->I_df_d || !out->I_df_u || !out->F) return CRT_ERR_BAD_ARG;
+  if (!integ && (!out->I_dr || !out->I_df_d || !out->I_df_u || !out->F)) return CRT_ERR_BAD_ARG;
   const bool tri = scheme == CRT_SCHEME_N79 || scheme == CRT_SCHEME_ZQ;
   const int nextra = scheme == CRT_SCHEME_N79 ? 2 : (scheme == CRT_SCHEME_ZQ || scheme == CRT_SCHEME_G77 || scheme == CRT_SCHEME_BF) ? 3 : 0;
-  if (nextra >= 1 && !out->x0) return CRT_ERR_BAD_ARG;
-  if (nextra >= 2 && !out->x1) return CRT_ERR_BAD_ARG;
-  if (nextra >= 3 && !out->x2) return CRT_ERR_BAD_ARG;
+  if (!integ) {
+    if (nextra >= 1 && !out->x0) return CRT_ERR_BAD_ARG;
+    if (nextra >= 2 && !out->x1) return CRT_ERR_BAD_ARG;
+    if (nextra >= 3 && !out->x2) return CRT_ERR_BAD_ARG;
+  }
   if (nz < 2) return CRT_ERR_SHAPE;
   if (scheme == CRT_SCHEME_N79 && nz < 3) return CRT_ERR_SHAPE;  // td[1]/tb[1] of _solve_n79.py:85-92
   double mu_s = 0.501;
@@ -308,6 +311,10 @@ static int solve_impl(int scheme, const crt_columns* cols, const crt_bands* band
   sa.o[6] = out->x2;
   sa.mu_s = mu_s;
   sa.f32 = f32;
+  if (integ) {
+    if (scheme == CRT_SCHEME_ZQ_PA) return CRT_ERR_UNSUPPORTED;
+    return tri ? launch_tridiag_int(scheme, sa, *integ, s) : launch_closed_int(scheme, sa, *integ, s);
+  }
   if (scheme == CRT_SCHEME_ZQ_PA)
     return launch_zqpa(sa, static_cast<double*>(workspace) + (size_t)ncol * sa.reclen, s);
   const int force = (flags & CRT_FLAG_DIRECT_STORES) ? 1 : 0;
@@ -386,6 +393,22 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
   a.totals = totals;
   hipLaunchKernelGGL(k_absorb_bandsum, dim3(a.ncol), dim3(EB), 0, static_cast<hipStream_t>(stream), a);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+}
+
+int crt_hip_integrated_f64(int scheme, const crt_columns* cols, const crt_bands* bands, const crt_options* opts,
+                           const double* band_w, int32_t ngroup, double* aI, double* aI_sl, double* aI_sh, double* totals,
+                           void* workspace, size_t workspace_bytes, crt_stream_t stream) {
+  if (!band_w || !aI || !aI_sl || !aI_sh || ngroup <= 0 || ngroup > INT_MAXG || !cols) return CRT_ERR_BAD_ARG;
+  IntArgs ia;
+  ia.lai = cols->lai;
+  ia.band_w = band_w;
+  ia.ngroup = ngroup;
+  ia.aI = aI;
+  ia.aI_sl = aI_sl;
+  ia.aI_sh = aI_sh;
+  ia.totals = totals;
+  crt_outputs none = {};
+  return solve_impl(scheme, cols, bands, opts, &none, workspace, workspace_bytes, stream, 0, &ia);
 }
 
 int crt_hip_absorb_f64(const crt_columns* cols, const crt_bands* bands, const double* I_dr, const double* I_df_d,

@@ -202,6 +202,143 @@ __device__ inline double fast_rcp(double x) {
 // value -> <= 8 ulp; the rule depends on j only, so every kernel variant produces the same bits.
 __device__ inline bool exact_level(int j) { return (j & 7) == 0; }
 
+// ------------------------------------------------------------------------------------------
+// Integrated-output path (no profiles written): per column and band group g (weights w_g[b], diagnostics.py:81)
+//   Phi_g(j) = sum_b w_g[b] (I_dr + I_df_d - I_df_u)(j, b)            net downward flux at level j
+//   aI_g(k)  = Phi_g(k+1) - Phi_g(k)                                  == sum_b w_g[b] aI(k, b)      (model.py:609)
+//   aI_dr    = (1 - e^{-K_b dlai_k}) e^{-K_b lai_{k+1}} sum_b w_g[b] (1 - r - t)[b] I_dr0[b]       (model.py:617-621;
+//              I_dr factorises into band x level, so this needs ONE reduction per column)
+//   aI_sl = (aI - aI_dr) f_sl(k) + aI_dr,  aI_sh = (aI - aI_dr)(1 - f_sl(k))                       (model.py:628-634)
+// so only ngroup values per level are reduced across the bands (wave shuffles + one LDS pass per column).
+constexpr int INT_MAXG = 4;
+
+struct IntArgs {
+  const double* lai;     // [ncol][nz]
+  const double* band_w;  // [ngroup][nb]
+  int ngroup;
+  double* aI;            // [ncol][nz-1][ngroup]
+  double* aI_sl;
+  double* aI_sh;
+  double* totals;        // [ncol][ngroup][4]: incoming, reflected, transmitted, soil-reflected (may be NULL)
+};
+
+// Sum over each 16-lane DPP row, result in every lane of the row: 4 steps of (2 x v_mov_b32 dpp + v_add_f64), pure VALU
+// (a __shfl_xor butterfly over the whole wave goes through ds_bpermute: LDS-crossbar latency on every step, measured
+// 1.6 ms per 3e6 solves for the integrated 2s kernel against 1.0 ms for the kernel that writes full profiles).
+template <int CTRL>
+__device__ inline double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ inline double row_sum16(double v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror
+  return v;
+}
+// ... plus row_bcast15 / row_bcast31: the wave total ends up in lane 63 (only that lane is valid)
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_add_rows(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ inline double wave_sum_lane63(double v) {
+  v = row_sum16(v);
+  v = dpp_add_rows<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+  v = dpp_add_rows<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+  return v;
+}
+__device__ inline double wave_sum_all(double v) {  // sum over the 64 lanes (used once per column only)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// LDS layout of the partial sums: nslot = waves (ROWS = false: wave totals, 6 DPP steps per value) or 4 * waves
+// (ROWS = true: one partial per 16-lane row, 4 DPP steps per value, 4x the LDS):
+//   part[(j * nslot + slot) * INT_MAXG + g];  ends[((e * nslot + slot) * 2 + q) * INT_MAXG + g] with e = 0 ground / 1 top,
+//   q = 0 (I_dr + I_df_d) / 1 (I_df_u);  pdr[wave * INT_MAXG + g]
+struct IntLds {
+  double* part;
+  double* ends;
+  double* pdr;
+};
+
+template <bool ROWS>
+__device__ inline void int_accumulate(const IntLds& L, int nwave, int wave, int lane, int nz, int j, int ng, const double (&w)[INT_MAXG],
+                                      bool active, double idr, double dn, double up) {
+  const int nslot = ROWS ? nwave * 4 : nwave;
+  const int slot = ROWS ? wave * 4 + (lane >> 4) : wave;
+  const bool writer = ROWS ? (lane & 15) == 0 : lane == 63;
+  auto red = [](double v) { return ROWS ? row_sum16(v) : wave_sum_lane63(v); };
+  const double net = active ? idr + dn - up : 0.0;
+#pragma unroll
+  for (int g = 0; g < INT_MAXG; ++g)
+    if (g < ng) {
+      const double t = red(w[g] * net);
+      if (writer) L.part[(j * nslot + slot) * INT_MAXG + g] = t;
+    }
+  if (j == 0 || j == nz - 1) {
+    const int e = j == 0 ? 0 : 1;
+#pragma unroll
+    for (int g = 0; g < INT_MAXG; ++g)
+      if (g < ng) {
+        const double t0 = red(active ? w[g] * (idr + dn) : 0.0);
+        const double t1 = red(active ? w[g] * up : 0.0);
+        if (writer) {
+          L.ends[((e * nslot + slot) * 2 + 0) * INT_MAXG + g] = t0;
+          L.ends[((e * nslot + slot) * 2 + 1) * INT_MAXG + g] = t1;
+        }
+      }
+  }
+}
+
+// after the sweep (call with all threads of the workgroup): combine the partials and write the column's outputs
+template <bool ROWS>
+__device__ inline void int_finish(const IntLds& L, const IntArgs& ia, int nwave, int nz, int c, double Kb) {
+  __syncthreads();
+  const int ng = ia.ngroup, nrow = ROWS ? nwave * 4 : nwave;
+  const double* lai = ia.lai + (long long)c * nz;
+  for (int i = threadIdx.x; i < (nz - 1) * ng; i += blockDim.x) {
+    const int k = i / ng, g = i - k * ng;
+    double p0 = 0.0, p1 = 0.0, pd = 0.0;
+    for (int r = 0; r < nrow; ++r) {
+      p0 += L.part[(k * nrow + r) * INT_MAXG + g];
+      p1 += L.part[((k + 1) * nrow + r) * INT_MAXG + g];
+    }
+    for (int wv = 0; wv < nwave; ++wv) pd += L.pdr[wv * INT_MAXG + g];
+    const double dl = lai[k] - lai[k + 1];
+    const double fsl = exp(-Kb * ((lai[k] + lai[k + 1]) / 2));       // model.py:601-602
+    const double adr = (1 - exp(-Kb * dl)) * exp(-Kb * lai[k + 1]) * pd;  // :617-621
+    const double a = p1 - p0;                                          // :609
+    const double adf = a - adr;
+    const long long o = ((long long)c * (nz - 1) + k) * ng + g;
+    ia.aI[o] = a;
+    ia.aI_sl[o] = adf * fsl + adr;
+    ia.aI_sh[o] = adf * (1 - fsl);
+  }
+  if (ia.totals) {
+    for (int i = threadIdx.x; i < ng * 4; i += blockDim.x) {
+      const int g = i >> 2, q = i & 3;  // incoming (top, I_d), reflected (top, up), transmitted (ground, I_d), soil-reflected
+      const int e = q < 2 ? 1 : 0, which = q & 1;
+      double t = 0.0;
+      for (int r = 0; r < nrow; ++r) t += L.ends[((e * nrow + r) * 2 + which) * INT_MAXG + g];
+      ia.totals[((long long)c * ng + g) * 4 + q] = t;
+    }
+  }
+}
+
+__host__ __device__ inline size_t int_lds_doubles(int nz, int nwave, bool rows = false) {
+  const size_t nslot = rows ? (size_t)nwave * 4 : (size_t)nwave;
+  return (size_t)nz * nslot * INT_MAXG + 2 * nslot * 2 * INT_MAXG + (size_t)nwave * INT_MAXG;
+}
+
+int launch_closed_int(int scheme, const SolveArgs& a, const IntArgs& ia, hipStream_t s);
+int launch_tridiag_int(int scheme, const SolveArgs& a, const IntArgs& ia, hipStream_t s);
+
 // launchers implemented in the .hip files
 int launch_colpre(const ColArgs& a, hipStream_t s);
 int launch_closed(int scheme, const SolveArgs& a, hipStream_t s, int force);

@@ -697,7 +697,91 @@ int launch_io(const SolveArgs& a, hipStream_t s, int force) {
   return a.f32 ? launch_scheme<S, float>(a, s, force) : launch_scheme<S, double>(a, s, force);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_int: integrated outputs only (see IntArgs in crt_internal.hpp).  One workgroup per column, one lane per band; the
+// level values never leave the registers, the only cross-lane traffic is ngroup shuffle reductions per level.
+template <class S, typename TIO, int MAXT, bool ROWS>
+__global__ __launch_bounds__(MAXT) void k_int(SolveArgs a, IntArgs ia, int rec_dbl) {
+  extern __shared__ double lds[];
+  const int nb = a.nb, nz = a.nz, ng = ia.ngroup;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+  const int c = blockIdx.x;
+  {
+    const double* src = a.ws + (long long)c * a.reclen;
+    for (int i = tid; i < a.reclen; i += nthr) lds[i] = src[i];
+  }
+  __syncthreads();
+  const double* rec = lds;
+  IntLds L;
+  L.part = lds + rec_dbl;
+  L.ends = L.part + (size_t)nz * (ROWS ? nwave * 4 : nwave) * INT_MAXG;
+  L.pdr = L.ends + (size_t)2 * (ROWS ? nwave * 4 : nwave) * 2 * INT_MAXG;
+  const bool active = tid < nb;
+  const int b = active ? tid : 0;
+  const BandIn in = load_band<TIO>(a, c, b, S::SOIL);
+  S st;
+  st.init(rec, in, a);
+  double w[INT_MAXG];
+#pragma unroll
+  for (int g = 0; g < INT_MAXG; ++g) w[g] = (g < ng && active) ? ia.band_w[(long long)g * nb + b] : 0.0;
+#pragma unroll
+  for (int g = 0; g < INT_MAXG; ++g)
+    if (g < ng) {
+      const double t = wave_sum_all(w[g] * (1 - (in.r + in.t)) * in.I_dr0);
+      if (lane == 0) L.pdr[wave * INT_MAXG + g] = t;
+    }
+  for (int j = 0; j < nz; ++j) {
+    double val[S::NARR];
+    st.level(j, rec, nz, val);  // val[0..2] = I_dr, I_df_d, I_df_u for every scheme
+    int_accumulate<ROWS>(L, nwave, wave, lane, nz, j, ng, w, active, val[0], val[1], val[2]);
+  }
+  int_finish<ROWS>(L, ia, nwave, nz, c, rec[S_KB]);
+}
+
+template <class S, typename TIO>
+int launch_int(const SolveArgs& a, const IntArgs& ia, hipStream_t s) {
+  if (a.nb > 1024) return CRT_ERR_UNSUPPORTED;
+  const int nthr = ((a.nb + 63) / 64) * 64;
+  const int rec_dbl = (a.reclen + 1) & ~1;
+  // per-row partials (4 DPP steps per value) while they leave three workgroups per CU, else per-wave totals (6 steps):
+  // measured 2s 1e4x300x60: rows 0.625 ms, wave totals 0.80 ms, __shfl_xor butterflies 1.59 ms
+  const bool rows = (rec_dbl + int_lds_doubles(a.nz, nthr / 64, true)) * sizeof(double) <= 52 * 1024;
+  const size_t sh = (rec_dbl + int_lds_doubles(a.nz, nthr / 64, rows)) * sizeof(double);
+  if (sh > 160 * 1024) return CRT_ERR_UNSUPPORTED;
+  auto go = [&](auto kern) {
+    if (sh > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+      return (int)CRT_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, ia, rec_dbl);
+    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+  };
+  if (rows) {
+    if (nthr <= 256) return go(k_int<S, TIO, 256, true>);
+    if (nthr <= 512) return go(k_int<S, TIO, 512, true>);
+    return go(k_int<S, TIO, 1024, true>);
+  }
+  if (nthr <= 256) return go(k_int<S, TIO, 256, false>);
+  if (nthr <= 512) return go(k_int<S, TIO, 512, false>);
+  return go(k_int<S, TIO, 1024, false>);
+}
+
+template <class S>
+int launch_int_io(const SolveArgs& a, const IntArgs& ia, hipStream_t s) {
+  return a.f32 ? launch_int<S, float>(a, ia, s) : launch_int<S, double>(a, ia, s);
+}
+
 }  // namespace
+
+int launch_closed_int(int scheme, const SolveArgs& a, const IntArgs& ia, hipStream_t s) {
+  switch (scheme) {
+    case CRT_SCHEME_2S: return launch_int_io<Sch2s>(a, ia, s);
+    case CRT_SCHEME_4S: return launch_int_io<Sch4s>(a, ia, s);
+    case CRT_SCHEME_BL: return launch_int_io<SchBl>(a, ia, s);
+    case CRT_SCHEME_G77: return launch_int_io<SchG77<false>>(a, ia, s);
+    case CRT_SCHEME_BF: return launch_int_io<SchG77<true>>(a, ia, s);
+    default: return CRT_ERR_BAD_ARG;
+  }
+}
 
 void tune_closed(int key, int value) {
   if (key >= 0 && key < 8) g_tune[key] = value;

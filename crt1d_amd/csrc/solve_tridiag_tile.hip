@@ -24,6 +24,8 @@
 namespace crt {
 namespace {
 
+constexpr size_t MAX_WG_LDS = 160 * 1024;
+
 struct TriCfg {
   int T;        // levels per flush tile (divides M)
   int nck;      // checkpoints per lane
@@ -209,8 +211,6 @@ __global__ __launch_bounds__(MAXT) void k_tri_tile(SolveArgs a, TriCfg cfg) {
   }
 }
 
-constexpr size_t MAX_WG_LDS = 160 * 1024;
-
 template <class S, typename TIO, int M, int T, bool FUSED>
 int launch_mt(const SolveArgs& a, hipStream_t s, int nthr) {
   const int K = S::rows(a.nz);
@@ -234,6 +234,112 @@ int launch_mt(const SolveArgs& a, hipStream_t s, int nthr) {
   else
     hipLaunchKernelGGL((k_tri_tile<S, TIO, M, T, 1024, FUSED>), grid, block, sh, s, a, cfg);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
+// Integrated outputs only (IntArgs, crt_internal.hpp): the same checkpointed sweep, but instead of staging and flushing
+// profiles every level's net flux is reduced across the bands with ngroup wave shuffles.
+template <class S, typename TIO, int M, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_tri_int(SolveArgs a, IntArgs ia, int off_ck, int off_int) {
+  extern __shared__ double lds[];
+  const int nb = a.nb, nz = a.nz, ng = ia.ngroup;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+  const int c = blockIdx.x;
+  {
+    const double* src = a.ws + (long long)c * a.reclen;
+    for (int i = tid; i < a.reclen; i += nthr) lds[i] = src[i];
+  }
+  __syncthreads();
+  const double* rec = lds;
+  double* ck = lds + off_ck + tid;  // [nck][2][nthr]
+  IntLds L;
+  L.part = lds + off_int;
+  L.ends = L.part + (size_t)nz * nwave * INT_MAXG;
+  L.pdr = L.ends + (size_t)2 * nwave * 2 * INT_MAXG;
+  const bool active = tid < nb;
+  const int b = active ? tid : 0;
+  S st;
+  st.template init<TIO>(rec, a, c, b);
+  const double bc = st.band_const();
+  const long long ib = (long long)c * a.col_stride + b;
+  const double leaf_a = 1 - (ldio<TIO>(a.leaf_r, ib) + ldio<TIO>(a.leaf_t, ib));
+  double w[INT_MAXG];
+#pragma unroll
+  for (int g = 0; g < INT_MAXG; ++g) w[g] = (g < ng && active) ? ia.band_w[(long long)g * nb + b] : 0.0;
+#pragma unroll
+  for (int g = 0; g < INT_MAXG; ++g)
+    if (g < ng) {
+      const double t = wave_sum_all(w[g] * leaf_a * bc);
+      if (lane == 0) L.pdr[wave * INT_MAXG + g] = t;
+    }
+  const int K = S::rows(nz);
+  double e, f;
+  st.first(rec, nz, e, f);
+  ck[0] = e;
+  ck[nthr] = f;
+  for (int k = 0; k + 1 < K; ++k) {
+    st.advance(k, rec, nz, e, f);
+    if ((k + 1) % M == 0) {
+      const int sidx = (k + 1) / M;
+      ck[(2 * sidx) * nthr] = e;
+      ck[(2 * sidx + 1) * nthr] = f;
+    }
+  }
+  for (int seg = (K - 1) / M; seg >= 0; --seg) {
+    const int k0 = seg * M;
+    const int kend = min(k0 + M - 1, K - 1);
+    double be[M], bf[M];
+    be[0] = ck[(2 * seg) * nthr];
+    bf[0] = ck[(2 * seg + 1) * nthr];
+#pragma unroll
+    for (int i = 1; i < M; ++i) {
+      be[i] = be[i - 1];
+      bf[i] = bf[i - 1];
+      if (k0 + i <= kend) st.advance(k0 + i - 1, rec, nz, be[i], bf[i]);
+    }
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+      const int k = k0 + i;
+      if (k <= kend) {
+        double o[S::NST];
+        if (k == K - 1)
+          st.top(rec, nz, be[i], bf[i], o);
+        else
+          st.back(k, rec, nz, be[i], bf[i], o);
+        if (k < nz) int_accumulate<false>(L, nwave, wave, lane, nz, k, ng, w, active, bc * rec[REC_HDR + k], o[0], o[1]);
+      }
+    }
+  }
+  int_finish<false>(L, ia, nwave, nz, c, rec[S_KB]);
+}
+
+template <class S, typename TIO, int M>
+int launch_int_m(const SolveArgs& a, const IntArgs& ia, hipStream_t s, int nthr) {
+  const int K = S::rows(a.nz);
+  const int nck = (K - 1) / M + 1;
+  const int off_ck = (a.reclen + 1) & ~1;
+  const int off_int = off_ck + 2 * nck * nthr;
+  const size_t sh = ((size_t)off_int + int_lds_doubles(a.nz, nthr / 64)) * sizeof(double);
+  if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
+  auto go = [&](auto kern) {
+    if (sh > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+      return (int)CRT_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, ia, off_ck, off_int);
+    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+  };
+  if (nthr <= 256) return go(k_tri_int<S, TIO, M, 256>);
+  if (nthr <= 512) return go(k_tri_int<S, TIO, M, 512>);
+  return go(k_tri_int<S, TIO, M, 1024>);
+}
+
+template <class S, typename TIO>
+int launch_int_scheme(const SolveArgs& a, const IntArgs& ia, hipStream_t s) {
+  if (a.nb > 1024) return CRT_ERR_UNSUPPORTED;
+  const int nthr = ((a.nb + 63) / 64) * 64;
+  int st = launch_int_m<S, TIO, 8>(a, ia, s, nthr);  // small M: fewer registers, LDS is not the constraint here
+  if (st == CRT_ERR_UNSUPPORTED) st = launch_int_m<S, TIO, 16>(a, ia, s, nthr);
+  return st;
 }
 
 int g_tri_tune[4] = {0, 0, 0, 0};  // [0] force M (8/12/16), [1] force T (4/8)
@@ -294,6 +400,13 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 64
 
 void tune_tridiag(int key, int value) {
   if (key >= 0 && key < 4) g_tri_tune[key] = value;
+}
+
+int launch_tridiag_int(int scheme, const SolveArgs& a, const IntArgs& ia, hipStream_t s) {
+  if (scheme == CRT_SCHEME_N79)
+    return a.f32 ? launch_int_scheme<TriN79, float>(a, ia, s) : launch_int_scheme<TriN79, double>(a, ia, s);
+  if (scheme == CRT_SCHEME_ZQ) return a.f32 ? launch_int_scheme<TriZq, float>(a, ia, s) : launch_int_scheme<TriZq, double>(a, ia, s);
+  return CRT_ERR_BAD_ARG;
 }
 
 // returns CRT_OK with done = false when the column-tile kernel does not apply (caller falls back)

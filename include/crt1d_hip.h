@@ -194,6 +194,15 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
                                double* aI_sh, double* totals, crt_stream_t stream);
 
 /*
+ * Fused solve + epilogue: the integrated outputs of crt_hip_absorb_bandsum_f64 (same shapes and meaning) straight from
+ * the inputs, WITHOUT writing any profile to memory (bytes per solve drop from ~2 kB to ~40 B; the variant SURVEY.md
+ * section 8(d) asks to report separately).  Schemes: 2s, 4s, bl, g77, bf, n79, zq; nb <= 1024.
+ */
+int crt_hip_integrated_f64(int scheme, const crt_columns* cols, const crt_bands* bands, const crt_options* opts,
+                           const double* band_w, int32_t ngroup, double* aI, double* aI_sl, double* aI_sh, double* totals,
+                           void* workspace, size_t workspace_bytes, crt_stream_t stream);
+
+/*
  * Per-band layer absorption (model.py:573-647 `_calc_absorption`): out7 = {aI, aI_df, aI_dr, aI_sh, aI_sl, aI_df_sl,
  * aI_df_sh}, each [ncol][nz-1][nb]; laim, f_slm [ncol][nz-1].
  */

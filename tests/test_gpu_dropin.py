@@ -235,3 +235,26 @@ def test_dist_paths_on_the_hip_kernels(oracle, scheme):
     np.testing.assert_allclose(rc["aI"].cpu().numpy(), ab["aI"] @ wn.T, rtol=1e-9, atol=1e-12)
     refl = (ref["I_df_u"][:, -1] @ wn.T) / ((ref["I_dr"][:, -1] + ref["I_df_d"][:, -1]) @ wn.T)
     np.testing.assert_allclose(rc["reflectance"].cpu().numpy(), refl, rtol=1e-9)
+
+
+@pytest.mark.parametrize("scheme", ["2s", "4s", "bl", "g77", "bf", "n79", "zq"])
+@pytest.mark.parametrize("shape", [(19, 300, 60), (7, 107, 61), (5, 64, 13), (3, 30, 9), (2, 513, 100)])
+def test_integrated_kernel_equals_solve_plus_epilogue(scheme, shape):
+    """crt_hip_integrated_f64 (no profiles written) == crt_hip_<scheme>_f64 followed by crt_hip_absorb_bandsum_f64.
+    The fused kernel differences Phi(k+1) - Phi(k) of band-summed net fluxes instead of summing per-band differences:
+    same numbers up to rounding relative to the flux (1e-16 * |Phi| / |aI|)."""
+    import torch
+
+    from crt1d_amd import batched, spectra, synth
+
+    ncol, nb, nz = shape
+    d = synth.make_columns(ncol, nb, nz, seed=23, uniform_dlai=(nz % 2 == 0))
+    cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
+    w = torch.as_tensor(spectra.band_weights(d["wle"])).cuda()
+    fused = batched.solve_integrated(scheme, cols, bands, w)
+    sol = batched.solve(scheme, cols, bands)
+    ref = batched.absorb_bandsum(cols, bands, sol, w)
+    flux = ref["totals"][:, :, 0].abs().amax()  # scale of the fluxes being differenced
+    for k in ("aI", "aI_sl", "aI_sh", "totals"):
+        err = float((fused[k] - ref[k]).abs().max() / flux)
+        assert err < 1e-13, (k, err)
