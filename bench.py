@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--nz", type=int, default=60)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
                     help="storage type of spectra/profiles; arithmetic is fp64 either way (f32 = config 5 variant, not the headline)")
+    ap.add_argument("--variant", default="profiles", choices=["profiles", "integrated"],
+                    help="'integrated': fused solve + absorption + band integrals (crt_hip_integrated_f64), no profiles written; "
+                         "a separately reported variant with its own byte count, NOT the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; 'gloo' + --share-device rehearses the N>1 code path on a one-GPU box")
@@ -154,7 +157,13 @@ def main():
 
         d = {k: (v.astype(np.float32) if k in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r") else v) for k, v in d.items()}
     bands = batched.Bands.from_host(d, dev)
-    plan = batched.Plan(scheme, cols, bands)
+    NG = 3  # PAR, NIR, solar
+    if a.variant == "integrated":
+        from crt1d_amd import spectra
+
+        plan = batched.IntegratedPlan(scheme, cols, bands, torch.as_tensor(spectra.band_weights(d["wle"])).to(dev))
+    else:
+        plan = batched.Plan(scheme, cols, bands)
     stream = torch.cuda.current_stream(dev)
 
     def barrier():
@@ -202,6 +211,8 @@ def main():
     k0_ms = e0.elapsed_time(e1) / 10
 
     bps = bytes_per_solve(scheme, nz, 4 if a.dtype == "f32" else 8)
+    if a.variant == "integrated":  # B = s n_in + s n_red (nz-1) / nb  (SURVEY 8(d)); n_red = 3 quantities x NG groups
+        bps = 8 * N_IO[scheme][0] + 8 * 3 * NG * (nz - 1) / nb
     alg_bytes = bps * ncol * nb  # per launch, this GPU
     achieved = alg_bytes / (k_ms_avg * 1e-3) / 1e9
 
@@ -229,7 +240,8 @@ def main():
     del buf, src
 
     out = {
-        "metric": "(column x band) solves/sec at 60 layers" if nz == 60 else f"(column x band) solves/sec at {nz} layers",
+        "metric": ("(column x band) solves/sec at 60 layers" if nz == 60 else f"(column x band) solves/sec at {nz} layers")
+                  + (" [integrated outputs only]" if a.variant == "integrated" else ""),
         "value": value,
         "unit": "solves/s",
         "n_gpus": world,
@@ -250,12 +262,13 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": KERNEL_NAMES[scheme],
+            "kernel": KERNEL_NAMES[scheme] if a.variant == "profiles" else ("k_int" if scheme in ("2s", "4s", "bl", "g77", "bf") else "k_tri_int"),
+            "note": None if a.variant == "profiles" else "integrated variant is compute-bound: the HBM fraction is informational only",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": load_pmc_traffic(scheme, ncol, nb, nz) if a.dtype == "f64" else None,
+            "traffic": load_pmc_traffic(scheme, ncol, nb, nz) if (a.dtype == "f64" and a.variant == "profiles") else None,
             "algorithmic_bytes_per_launch": alg_bytes,
             "bytes_per_solve": bps,
             "kernel_ms_avg": k_ms_avg,

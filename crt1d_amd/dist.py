@@ -33,7 +33,8 @@ def _default_fns():
     return batched.solve, batched.absorb_bandsum
 
 
-def solve_sharded(scheme, cols, bands, band_w, *, partition="column", group=None, solve_fn=None, epilogue_fn=None, **opts):
+def solve_sharded(scheme, cols, bands, band_w, *, partition="column", group=None, solve_fn=None, epilogue_fn=None,
+                  keep_profiles=True, integrated_fn=None, **opts):
     """Solve this rank's shard and return spectrally integrated results.
 
     ``cols`` / ``bands``: the FULL problem (objects with ``.ncol``, ``.nb``, ``.slice(lo, hi)``, ``.band_slice(lo, hi)``;
@@ -43,24 +44,35 @@ def solve_sharded(scheme, cols, bands, band_w, *, partition="column", group=None
       ``aI, aI_sl, aI_sh``  ``(ncol_local, nz-1, ngroup)``, ``totals (ncol_local, ngroup, 4)``, ``reflectance (ncol_local, ngroup)``,
       ``columns`` = (lo, hi) of the columns these rows describe, and ``profiles`` = this rank's full (unreduced) solver outputs.
     With ``partition="band"`` every rank ends up with the complete integrated result for all columns.
+    ``keep_profiles=False`` uses the fused kernel (``crt_hip_integrated_f64``): no profile is ever written to HBM and
+    ``profiles`` is ``None``.
     """
     if solve_fn is None or epilogue_fn is None:
         s, e = _default_fns()
         solve_fn = solve_fn or s
         epilogue_fn = epilogue_fn or e
+    if not keep_profiles:
+        if integrated_fn is None:
+            from . import batched
+
+            integrated_fn = batched.solve_integrated
+        fused = integrated_fn
+        solve_fn = lambda sch, c, b, **o: None  # noqa: E731
+        epilogue_fn = None
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if partition == "column":
         lo, hi = block_range(cols.ncol, rank, world)
         c, b = cols.slice(lo, hi), bands.slice(lo, hi)
         sol = solve_fn(scheme, c, b, **opts)
-        res = epilogue_fn(c, b, sol, band_w)
+        res = epilogue_fn(c, b, sol, band_w) if keep_profiles else dict(fused(scheme, c, b, band_w, **opts))
         col_range = (lo, hi)
     elif partition == "band":
         lo, hi = block_range(bands.nb, rank, world)
         b = bands.band_slice(lo, hi)
         sol = solve_fn(scheme, cols, b, **opts)
-        res = epilogue_fn(cols, b, sol, band_w[:, lo:hi].contiguous())
+        bw = band_w[:, lo:hi].contiguous()
+        res = epilogue_fn(cols, b, sol, bw) if keep_profiles else dict(fused(scheme, cols, b, bw, **opts))
         if world > 1:
             keys = ("aI", "aI_sl", "aI_sh", "totals")
             flat = torch.cat([res[k].reshape(-1) for k in keys])  # one packed message

@@ -227,6 +227,10 @@ def test_dist_paths_on_the_hip_kernels(oracle, scheme):
     assert rc["columns"] == (0, 23) and rb["columns"] == (0, 23)
     for k in ("aI", "aI_sl", "aI_sh", "totals", "reflectance"):
         assert torch.equal(rc[k], rb[k]), k
+    rf = solve_sharded(scheme, cols, bands, w, partition="band", keep_profiles=False)  # fused kernel, no profiles
+    assert rf["profiles"] is None
+    for k in ("aI", "aI_sl", "aI_sh", "totals", "reflectance"):
+        assert float((rf[k] - rc[k]).abs().max()) <= 1e-12 * float(rc["totals"].abs().max()), k
     oc = oracle.Columns(d["psi"], d["lai"], mla=d["mla"], g_kind=d["g_kind"], g_param=d["g_param"])
     kw = dict(I_dr0=d["I_dr0"], I_df0=d["I_df0"], leaf_r=d["leaf_r"], leaf_t=d["leaf_t"], soil_r=d["soil_r"])
     ref = oracle.SOLVERS[scheme](oc, **kw)
