@@ -100,6 +100,23 @@ class Columns:
     def device(self):
         return self.lai.device
 
+    def validate(self):
+        """The orientation checks ``Model._check_inputs`` makes per column (``crt1d/model.py:244-246``), for the whole
+        batch (one device->host sync): lai strictly decreasing with level, lai[:, -1] == 0, 0 <= psi < pi/2."""
+        import math
+
+        lai = self.lai
+        ok = bool((lai[:, :-1] > lai[:, 1:]).all()) and bool((lai[:, -1] == 0).all())
+        if not ok:
+            raise AssertionError("lai must decrease strictly from index 0 (ground, total LAI) to 0 at the canopy top")
+        if not bool(((self.psi >= 0) & (self.psi < math.pi / 2)).all()):
+            raise AssertionError("psi must be in [0, pi/2)")
+        if not bool(((self.g_kind >= 0) & (self.g_kind <= 6)).all()):
+            raise ValueError("invalid leaf-angle kind")
+        if bool((self.g_kind == 6).any()) and (self.g_table is None or self.g_at_psi is None):
+            raise ValueError("columns with g_kind = G_TABLE need g_table and g_at_psi")
+        return self
+
     def slice(self, lo, hi):
         """Columns [lo, hi) as a view (used by the column-sharded multi-GPU path)."""
         g = lambda t: None if t is None else t[lo:hi]  # noqa: E731

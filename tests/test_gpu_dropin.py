@@ -262,3 +262,19 @@ def test_integrated_kernel_equals_solve_plus_epilogue(scheme, shape):
     for k in ("aI", "aI_sl", "aI_sh", "totals"):
         err = float((fused[k] - ref[k]).abs().max() / flux)
         assert err < 1e-13, (k, err)
+
+
+def test_columns_validate():
+    import torch
+
+    from crt1d_amd import batched, synth
+
+    d = synth.make_columns(6, 8, 10)
+    cols = batched.Columns.from_host(d).validate()
+    bad = dict(d, lai=d["lai"][:, ::-1].copy())
+    with pytest.raises(AssertionError):
+        batched.Columns.from_host(bad).validate()
+    bad = dict(d, g_kind=np.full(6, 6, dtype=np.int32))
+    with pytest.raises(ValueError):
+        batched.Columns.from_host(bad).validate()
+    assert cols.ncol == 6 and cols.nz == 10
