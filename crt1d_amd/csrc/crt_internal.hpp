@@ -348,6 +348,7 @@ void tune_closed(int key, int value);
 void tune_tridiag(int key, int value);
 int launch_tridiag_tile(int scheme, const SolveArgs& a, hipStream_t s, bool& done);
 int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s);
+int launch_zqpa_wave(const SolveArgs& g, hipStream_t s);  // per-wave fallback of the computational-grid solve
 __host__ __device__ inline int zqpa_M(int nz) { return nz < 100 ? nz : 100; }
 void host_quad_nodes(double mu_s, double* psi_nodes);
 

@@ -21,8 +21,11 @@ namespace {
 
 constexpr int TB = 64;  // one wavefront per workgroup
 
-struct EF {
-  double* base;  // lane-private column of the [row][TB] LDS array
+// Forward-sweep pairs of one lane.  EfLds: a lane-private column of a [row][TB] LDS array.
+struct EfLds {
+  double* base;
+  template <typename A>
+  __device__ inline EfLds(const A&, const Item&, double* lds_ef) : base(lds_ef + threadIdx.x) {}
   __device__ inline void put(int k, double e, double f) {
     base[(2 * k) * TB] = e;
     base[(2 * k + 1) * TB] = f;
@@ -33,84 +36,94 @@ struct EF {
   }
 };
 
+// EfOut: nz beyond what a CU's LDS holds (16 nz bytes per lane).  Pair k is parked in row k of this lane's own output
+// elements, which the back sweep overwrites with the results of level k right after reading the pair back, so no
+// extra memory is needed.  fp64 outputs: e -> I_df_d, f -> I_df_u.  f32 storage: the two 32-bit halves of e -> I_df_d, I_df_u and
+// of f -> I_dr, F (bit-exact, so the f32 variant stays the rounded fp64 result).
+template <typename TIO>
+struct EfOut;
+template <>
+struct EfOut<double> {
+  double *pe, *pf;
+  long long nb;
+  __device__ inline EfOut(const SolveArgs& a, const Item& it, double*) : nb(a.nb) {
+    const long long o = (long long)it.c * a.nz * a.nb + it.b;
+    pe = static_cast<double*>(a.o[1]) + o;
+    pf = static_cast<double*>(a.o[2]) + o;
+  }
+  __device__ inline void put(int k, double e, double f) {
+    pe[k * nb] = e;
+    pf[k * nb] = f;
+  }
+  __device__ inline void get(int k, double& e, double& f) const {
+    e = pe[k * nb];
+    f = pf[k * nb];
+  }
+};
+template <>
+struct EfOut<float> {
+  int* p[4];
+  long long nb;
+  __device__ inline EfOut(const SolveArgs& a, const Item& it, double*) : nb(a.nb) {
+    const long long o = (long long)it.c * a.nz * a.nb + it.b;
+    for (int i = 0; i < 4; ++i) p[i] = static_cast<int*>(a.o[i]) + o;
+  }
+  __device__ inline void put(int k, double e, double f) {
+    p[1][k * nb] = __double2hiint(e);
+    p[2][k * nb] = __double2loint(e);
+    p[0][k * nb] = __double2hiint(f);
+    p[3][k * nb] = __double2loint(f);
+  }
+  __device__ inline void get(int k, double& e, double& f) const {
+    e = __hiloint2double(p[1][k * nb], p[2][k * nb]);
+    f = __hiloint2double(p[0][k * nb], p[3][k * nb]);
+  }
+};
+
+// all NOUT outputs of level k for this lane's band (same expressions as the column-tile kernel: S::emit)
+template <class S, typename TIO>
+__device__ inline void emit_level(const SolveArgs& a, const double* rec, const Item& it, int k, double bc, double invmu,
+                                  const double (&v)[S::NST]) {
+  d2 st2[S::NST], o2[S::NOUT];
+#pragma unroll
+  for (int q = 0; q < S::NST; ++q) st2[q] = d2{v[q], v[q]};
+  S::emit(rec, a.nz, k, d2{bc, bc}, invmu, st2, o2);
+#pragma unroll
+  for (int i = 0; i < S::NOUT; ++i) {
+    const int rows = S::out_rows(i, a.nz);
+    if (k < rows) __builtin_nontemporal_store((TIO)o2[i].x, outp<TIO>(a.o[i]) + ((long long)it.c * rows + k) * a.nb + it.b);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
-// n79: crt1d/solvers/_solve_n79.py:70-155 (scheme arithmetic in tri_schemes.hpp, shared with the column-tile kernel)
-template <typename TIO, bool USE_LDS>
-__global__ __launch_bounds__(TB) void k_n79(SolveArgs a, int rec_lds_doubles) {
+// One lane = one (column, band) system; scheme arithmetic in tri_schemes.hpp (shared with the column-tile kernel).
+//   n79: crt1d/solvers/_solve_n79.py:70-155     zq: crt1d/solvers/_solve_zq.py:74-219
+// The pair of the last even row stays in registers; pairs 0 .. K-2 go through EF.
+template <class S, typename TIO, bool USE_LDS, class EF>
+__global__ __launch_bounds__(TB) void k_tri_wave(SolveArgs a, int rec_lds_doubles) {
   extern __shared__ double lds[];
   const Item it = locate<TB, 1>(a.ncol, a.nb);
   const double* rec = stage_records<TB, 1, USE_LDS>(a, it, lds);
   if (!it.active) return;
-  EF ef{lds + rec_lds_doubles + threadIdx.x};
-  const int nz = a.nz, nb = a.nb;
-  TriN79 st;
+  EF ef(a, it, lds + rec_lds_doubles);
+  const int nz = a.nz, K = S::rows(nz);
+  S st;
   st.template init<TIO>(rec, a, it.c, it.b);
   const double bc = st.band_const(), invmu = rec[S_INVMU];
 
   double e, f;
   st.first(rec, nz, e, f);
-  ef.put(0, e, f);
-  for (int k = 0; k + 1 < nz; ++k) {
+  for (int k = 0; k + 1 < K; ++k) {
+    ef.put(k, e, f);
     st.advance(k, rec, nz, e, f);
-    ef.put(k + 1, e, f);
   }
-  long long o = ((long long)it.c * nz + (nz - 1)) * nb + it.b;
-  long long om = ((long long)it.c * (nz - 1) + (nz - 2)) * nb + it.b;
-  for (int k = nz - 1; k >= 0; --k, o -= nb) {
-    double v[TriN79::NST];
+  double v[S::NST];
+  st.top(rec, nz, e, f, v);
+  emit_level<S, TIO>(a, rec, it, K - 1, bc, invmu, v);
+  for (int k = K - 2; k >= 0; --k) {
     ef.get(k, e, f);
-    if (k == nz - 1) {
-      st.top(rec, nz, e, f, v);
-    } else {
-      st.back(k, rec, nz, e, f, v);
-      __builtin_nontemporal_store((TIO)v[2], outp<TIO>(a.o[4]) + om);
-      __builtin_nontemporal_store((TIO)v[3], outp<TIO>(a.o[5]) + om);
-      om -= nb;
-    }
-    const double idr = bc * rec[REC_HDR + k];
-    __builtin_nontemporal_store((TIO)idr, outp<TIO>(a.o[0]) + o);
-    __builtin_nontemporal_store((TIO)v[0], outp<TIO>(a.o[1]) + o);
-    __builtin_nontemporal_store((TIO)v[1], outp<TIO>(a.o[2]) + o);
-    __builtin_nontemporal_store((TIO)(idr * invmu + 2 * v[0] + 2 * v[1]), outp<TIO>(a.o[3]) + o);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// zq: crt1d/solvers/_solve_zq.py:74-219
-template <typename TIO, bool USE_LDS>
-__global__ __launch_bounds__(TB) void k_zq(SolveArgs a, int rec_lds_doubles) {
-  extern __shared__ double lds[];
-  const Item it = locate<TB, 1>(a.ncol, a.nb);
-  const double* rec = stage_records<TB, 1, USE_LDS>(a, it, lds);
-  if (!it.active) return;
-  EF ef{lds + rec_lds_doubles + threadIdx.x};
-  const int m = a.nz, nb = a.nb;
-  TriZq st;
-  st.template init<TIO>(rec, a, it.c, it.b);
-  const double bc = st.band_const(), invmu = rec[S_INVMU];
-
-  double e, f;
-  st.first(rec, m, e, f);
-  ef.put(0, e, f);
-  for (int k = 0; k < m; ++k) {
-    st.advance(k, rec, m, e, f);
-    ef.put(k + 1, e, f);
-  }
-  double v[TriZq::NST];
-  ef.get(m, e, f);
-  st.top(rec, m, e, f, v);
-  long long o = ((long long)it.c * m + (m - 1)) * nb + it.b;
-  for (int k = m - 1; k >= 0; --k, o -= nb) {
-    ef.get(k, e, f);
-    st.back(k, rec, m, e, f, v);
-    const double S = bc * rec[REC_HDR + k];
-    __builtin_nontemporal_store((TIO)S, outp<TIO>(a.o[0]) + o);                                   // :219
-    __builtin_nontemporal_store((TIO)v[0], outp<TIO>(a.o[1]) + o);                                // :198
-    __builtin_nontemporal_store((TIO)v[1], outp<TIO>(a.o[2]) + o);                                // :200
-    __builtin_nontemporal_store((TIO)(S * invmu + 2 * v[1] + 2 * v[0]), outp<TIO>(a.o[3]) + o);   // :202
-    __builtin_nontemporal_store((TIO)v[2], outp<TIO>(a.o[4]) + o);                                // :197
-    __builtin_nontemporal_store((TIO)v[3], outp<TIO>(a.o[5]) + o);                                // :199
-    __builtin_nontemporal_store((TIO)(S * invmu + 2 * v[3] + 2 * v[2]), outp<TIO>(a.o[6]) + o);   // :201
+    st.back(k, rec, nz, e, f, v);
+    emit_level<S, TIO>(a, rec, it, k, bc, invmu, v);
   }
 }
 
@@ -127,6 +140,29 @@ int set_lds_limit(K kern, size_t bytes) {
 
 }  // namespace
 
+template <class S, typename TIO>
+int launch_wave(const SolveArgs& a, hipStream_t s) {
+  const long long items = (long long)a.ncol * a.nb;
+  const long long nblk = (items + TB - 1) / TB;
+  if (nblk > 0x7fffffffLL) return CRT_ERR_UNSUPPORTED;
+  const size_t ef_lds = (size_t)(S::rows(a.nz) - 1) * 2 * TB * sizeof(double);
+  const long long cols_per_block = (TB - 1) / a.nb + 2;
+  const size_t rec_bytes = (size_t)cols_per_block * a.reclen * sizeof(double);
+  const bool ef_in_lds = ef_lds + (rec_bytes <= 32 * 1024 ? rec_bytes : 0) <= MAX_WG_LDS;
+  const bool use_lds = rec_bytes <= (ef_in_lds ? 32 * 1024 : 64 * 1024);  // records in LDS, else read through the cache
+  const size_t rec_doubles = use_lds ? rec_bytes / sizeof(double) : 0;
+  const size_t sh = (ef_in_lds ? ef_lds : 0) + rec_doubles * sizeof(double);
+  if (!ef_in_lds && (S::NOUT < 4 || a.nz < S::rows(a.nz) - 1)) return CRT_ERR_UNSUPPORTED;  // nowhere to park the pairs
+  auto go = [&](auto kern) {
+    const int st = set_lds_limit(kern, sh);
+    if (st != CRT_OK) return st;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(TB), sh, s, a, (int)rec_doubles);
+    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+  };
+  if (ef_in_lds) return use_lds ? go(k_tri_wave<S, TIO, true, EfLds>) : go(k_tri_wave<S, TIO, false, EfLds>);
+  return use_lds ? go(k_tri_wave<S, TIO, true, EfOut<TIO>>) : go(k_tri_wave<S, TIO, false, EfOut<TIO>>);
+}
+
 template <typename TIO>
 int launch_tridiag_io(int scheme, const SolveArgs& a, hipStream_t s, int force) {
   if (force != 1) {  // column-tile kernel (solve_tridiag_tile.hip) when it applies; force = 1 keeps the per-wave kernels
@@ -134,40 +170,13 @@ int launch_tridiag_io(int scheme, const SolveArgs& a, hipStream_t s, int force) 
     const int st = launch_tridiag_tile(scheme, a, s, done);
     if (st != CRT_OK || done) return st;
   }
-  const long long items = (long long)a.ncol * a.nb;
-  const long long nblk = (items + TB - 1) / TB;
-  if (nblk > 0x7fffffffLL) return CRT_ERR_UNSUPPORTED;
-  const int pairs = (scheme == CRT_SCHEME_ZQ) ? a.nz + 1 : a.nz;
-  const size_t ef_bytes = (size_t)pairs * 2 * TB * sizeof(double);
-  const long long cols_per_block = (TB - 1) / a.nb + 2;
-  size_t rec_doubles = (size_t)cols_per_block * a.reclen;
-  bool use_lds = ef_bytes + rec_doubles * sizeof(double) <= MAX_WG_LDS && rec_doubles * sizeof(double) <= 32 * 1024;
-  if (!use_lds) rec_doubles = 0;
-  const size_t sh = ef_bytes + rec_doubles * sizeof(double);
-  if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;  // nz beyond what one wave's sweep state fits in a CU's LDS
-  dim3 grid((unsigned)nblk), block(TB);
-  int st;
-  if (scheme == CRT_SCHEME_N79) {
-    if (use_lds) {
-      if ((st = set_lds_limit(k_n79<TIO, true>, sh)) != CRT_OK) return st;
-      hipLaunchKernelGGL((k_n79<TIO, true>), grid, block, sh, s, a, (int)rec_doubles);
-    } else {
-      if ((st = set_lds_limit(k_n79<TIO, false>, sh)) != CRT_OK) return st;
-      hipLaunchKernelGGL((k_n79<TIO, false>), grid, block, sh, s, a, 0);
-    }
-  } else if (scheme == CRT_SCHEME_ZQ) {
-    if (use_lds) {
-      if ((st = set_lds_limit(k_zq<TIO, true>, sh)) != CRT_OK) return st;
-      hipLaunchKernelGGL((k_zq<TIO, true>), grid, block, sh, s, a, (int)rec_doubles);
-    } else {
-      if ((st = set_lds_limit(k_zq<TIO, false>, sh)) != CRT_OK) return st;
-      hipLaunchKernelGGL((k_zq<TIO, false>), grid, block, sh, s, a, 0);
-    }
-  } else {
-    return CRT_ERR_BAD_ARG;
-  }
-  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+  if (scheme == CRT_SCHEME_N79) return launch_wave<TriN79, TIO>(a, s);
+  if (scheme == CRT_SCHEME_ZQ) return launch_wave<TriZq, TIO>(a, s);
+  return CRT_ERR_BAD_ARG;
 }
+
+// zq_pa computational-grid solve when the column-tile kernel does not apply (nb > 1024)
+int launch_zqpa_wave(const SolveArgs& g, hipStream_t s) { return launch_wave<TriZqPa, double>(g, s); }
 
 int launch_tridiag(int scheme, const SolveArgs& a, hipStream_t s, int force) {
   return a.f32 ? launch_tridiag_io<float>(scheme, a, s, force) : launch_tridiag_io<double>(scheme, a, s, force);

@@ -429,21 +429,6 @@ int launch_tridiag_tile(int scheme, const SolveArgs& a, hipStream_t s, bool& don
 namespace crt {
 namespace {
 
-struct TriZqPa : TriZq {
-  static constexpr int NOUT = 2;
-  __host__ __device__ static inline int out_rows(int, int nz) { return nz; }
-  template <int ARR>
-  __device__ static inline double value(const double*, int, int, double, double, const double* tile, int stride, int idx) {
-    return tile[ARR * stride + idx];
-  }
-  static constexpr bool derived(int) { return false; }
-  static constexpr int staged_slot(int arr) { return arr; }
-  __device__ static inline void emit(const double*, int, int, d2, double, const d2 (&st)[NST], d2 (&o)[NOUT]) {
-    o[0] = st[0];
-    o[1] = st[1];
-  }
-};
-
 struct InterpArgs {
   int ncol, nb, nz, M, reclen;
   long long col_stride;
@@ -500,7 +485,7 @@ int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s) {
   bool done = false;
   int st = launch_scheme<TriZqPa, double>(g, s, done, 1);
   if (st != CRT_OK) return st;
-  if (!done) return CRT_ERR_UNSUPPORTED;  // nb > 1024 or nz too large for one workgroup's LDS
+  if (!done && (st = launch_zqpa_wave(g, s)) != CRT_OK) return st;  // nb > 1024: per-wave kernel (solve_tridiag.hip)
   InterpArgs ia;
   ia.ncol = a.ncol;
   ia.nb = a.nb;
@@ -513,7 +498,12 @@ int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s) {
   ia.upz = scratch + (size_t)a.ncol * M * a.nb;
   ia.I_dr0 = a.I_dr0;
   for (int i = 0; i < 4; ++i) ia.o[i] = a.o[i];
-  hipLaunchKernelGGL((k_zqpa_interp<double>), dim3(a.ncol), dim3(256), a.reclen * sizeof(double), s, ia);
+  const size_t sh = a.reclen * sizeof(double);
+  if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
+  if (sh > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_zqpa_interp<double>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+    return CRT_ERR_LAUNCH;
+  hipLaunchKernelGGL((k_zqpa_interp<double>), dim3(a.ncol), dim3(256), sh, s, ia);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 

@@ -223,5 +223,23 @@ struct TriZq {
   }
 };
 
+// ------------------------------------------------------------------------------------------
+// zq_pa computational-grid solve (crt1d/solvers/_solve_zq_pa.py:24-418): the zq system with nz := M, only the two
+// single-scattering interface fluxes are kept (see solve_tridiag_tile.hip, launch_zqpa).
+struct TriZqPa : TriZq {
+  static constexpr int NOUT = 2;
+  __host__ __device__ static inline int out_rows(int, int nz) { return nz; }
+  template <int ARR>
+  __device__ static inline double value(const double*, int, int, double, double, const double* tile, int stride, int idx) {
+    return tile[ARR * stride + idx];
+  }
+  static constexpr bool derived(int) { return false; }
+  static constexpr int staged_slot(int arr) { return arr; }
+  __device__ static inline void emit(const double*, int, int, d2, double, const d2 (&st)[NST], d2 (&o)[NOUT]) {
+    o[0] = st[0];
+    o[1] = st[1];
+  }
+};
+
 }  // namespace
 }  // namespace crt

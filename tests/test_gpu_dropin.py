@@ -186,7 +186,7 @@ def test_plan_flags_and_strided_outputs():
 
 
 @pytest.mark.parametrize("scheme", ["2s", "4s", "bl", "g77", "bf", "n79", "zq"])
-@pytest.mark.parametrize("shape", [(21, 300, 60), (5, 107, 61), (9, 64, 13), (40, 6, 20), (3, 130, 100)])
+@pytest.mark.parametrize("shape", [(21, 300, 60), (5, 107, 61), (9, 64, 13), (40, 6, 20), (3, 130, 100), (2, 40, 400), (1, 1500, 30)])
 def test_f32_storage_variant(scheme, shape):
     """crt_hip_*_f32: float spectra in, float profiles out, fp64 arithmetic.  Feeding the SAME (float-representable)
     inputs to the f64 entry point and rounding its outputs to float must give the identical bits (config 5:

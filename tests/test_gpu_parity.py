@@ -249,3 +249,24 @@ def test_error_conventions(torch_cuda):
         batched.solve("n79", cols, bands, tau_d_method="simpson")
     with pytest.raises(ValueError):
         batched.solve("nope", cols, bands)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("shape", [(1, 1, 2), (2, 5, 3), (1, 2151, 60), (2, 1025, 20), (2, 40, 400), (1, 8, 3000), (70000, 1, 5)])
+def test_extreme_shapes(torch_cuda, oracle, scheme, shape):
+    """Shapes outside the tuned kernels' range: nb > 1024 (no column-tile kernel), nz far beyond the LDS sweep state
+    (per-wave kernel parks the forward pairs in its own output rows), nz = 2, single band, very many columns."""
+    from crt1d_amd import batched, synth
+
+    ncol, nb, nz = shape
+    if scheme == "n79" and nz < 3:
+        pytest.skip("n79 needs nz >= 3 (_solve_n79.py:85-92)")
+    d = synth.make_columns(ncol, nb, nz, seed=5, uniform_dlai=(ncol % 2 == 1))
+    got = batched.solve(scheme, batched.Columns.from_host(d), batched.Bands.from_host(d))
+    nref = min(ncol, 4)  # the oracle checks the first columns; the rest must at least be finite
+    dr = {k: (v[:nref] if isinstance(v, np.ndarray) and v.shape[:1] == (ncol,) else v) for k, v in d.items()}
+    ref = oracle.SOLVERS[scheme](_oracle_cols(oracle, dr), **_kw(dr, scheme))
+    for k, v in got.items():
+        assert bool(torch_cuda.isfinite(v).all()), k
+        tol = 1e-8 if scheme in ("2s", "n79") else 1e-10
+        assert rel_profile_err(v[:nref].cpu().numpy(), ref[k]) <= tol, (k, rel_profile_err(v[:nref].cpu().numpy(), ref[k]))
