@@ -3,8 +3,8 @@
 
 Same entry points and bookkeeping for the hot path: ``Model(scheme, nlayers, **p)``, ``update_p``,
 ``assign_scheme``, ``run(**solver_options)`` (``model.py:296-320``), ``calc_absorption()``
-(``model.py:327-336,573-647``), ``out`` / ``out_extra`` / ``absorption``.  Presentation (``to_xr``, plots) is
-outside the hot-path scope; ``to_xr`` works when xarray happens to be installed and raises otherwise.
+(``model.py:327-336,573-647``), ``out`` / ``out_extra`` / ``absorption``.  ``to_dataset()`` returns the reference's
+output dataset as a plain container (``to_xr()`` converts it when xarray is installed); plots are out of scope.
 
 Multi-column use (the reference's ``run_sensitivity`` is a ``NotImplementedError`` stub, ``model.py:650-664``):
 :func:`run_columns` solves many independent canopies in one launch.
@@ -21,7 +21,7 @@ from .solvers import AVAILABLE_SCHEMES, RET_KEYS_ALL_SCHEMES
 from .solvers.common import KbFunction
 from .variables import VMD
 
-__all__ = ("Model", "run_columns")
+__all__ = ("Model", "Dataset", "run_columns")
 
 CANOPY_DESCRIPTION_KEYS = [
     "lai", "z", "dlai", "lai_tot", "lai_eff", "mla", "clump", "leaf_t", "leaf_r", "soil_r", "wl_leafsoil", "orient", "G_fn",
@@ -197,13 +197,83 @@ class Model:
         self.absorption = ab
         return self
 
+    def to_dataset(self, *, info=""):
+        """The reference's output dataset (``model.py:338-447``) as a plain :class:`Dataset`: same coordinates (``z, wl, zm,
+        wle``), data variables (solution, ``I_d``, grid, absorption, scheme extras named ``aI*_scheme``, geometry scalars),
+        dims, attributes and global attributes.  No xarray needed; :meth:`to_xr` converts when it is installed."""
+        from . import __version__
+        from .variables import da_attrs, dv_tuple
+
+        if self._run_count == 0:
+            raise Exception("Must run the model before creating the dataset.")
+        p = self._p
+        out = self.out_all
+        z, zm = np.asarray(p["z"]), np.asarray(p["zm"])
+        data_vars = {
+            "I_dr": dv_tuple("I_dr", out["I_dr"]),
+            "I_df_d": dv_tuple("I_df_d", out["I_df_d"]),
+            "I_df_u": dv_tuple("I_df_u", out["I_df_u"]),
+            "F": dv_tuple("F", out["F"]),
+            "I_d": dv_tuple("I_d", out["I_dr"] + out["I_df_d"]),
+            "dwl": dv_tuple("dwl", np.asarray(p["dwl"])),
+            "lai": dv_tuple("lai", np.asarray(p["lai"])),
+            "dlai": dv_tuple("dlai", np.asarray(p["dlai"])),
+        }
+        for k, v in (self.absorption or {}).items():  # standard absorption calculations (layer in-out)
+            data_vars[k] = dv_tuple(k, v)
+        for name, arr in self.out_extra.items():  # the scheme's own absorption outputs
+            if name[:2] != "aI":
+                continue
+            if arr.shape[0] == z.size:
+                dims = ("z", "wl")
+            elif arr.shape[0] == zm.size:
+                dims = ("zm", "wl")
+            else:
+                raise ValueError("Scheme absorption output has too many or too few levels.")
+            try:
+                attrs = da_attrs(name[:-7])  # without the `_scheme` suffix
+            except KeyError:
+                raise Exception(f"Scheme absorbance variable {name[:-7]} not found in vmd.")
+            data_vars[name] = (dims, arr, attrs)
+        data_vars.update(psi=dv_tuple("psi", p["psi"]), sza=dv_tuple("sza", np.rad2deg(p["psi"])), G=dv_tuple("G", p["G"]),
+                         K_b=dv_tuple("K_b", p["K_b"]))
+        coords = {"z": dv_tuple("z", z), "wl": dv_tuple("wl", np.asarray(p["wl"])), "zm": dv_tuple("zm", zm),
+                  "wle": dv_tuple("wle", np.asarray(p["wle"]))}
+        attrs = {"info": info, "scheme_name": self.scheme["name"], "scheme_long_name": self.scheme["long_name"],
+                 "scheme_short_name": self.scheme["short_name"], "crt1d_version": __version__}
+        return Dataset(coords, data_vars, attrs)
+
     def to_xr(self, *, info=""):
-        """Presentation layer of the reference (``model.py:338-447``): outside the hot-path scope."""
+        """``xarray.Dataset`` of the run (``model.py:338-447``); needs xarray, which the hot path itself does not."""
+        return self.to_dataset(info=info).to_xarray()
+
+
+class Dataset:
+    """Minimal labelled container: ``coords`` / ``data_vars`` map a name to ``(dims, array, attrs)``; ``attrs`` are global."""
+
+    def __init__(self, coords, data_vars, attrs):
+        self.coords, self.data_vars, self.attrs = dict(coords), dict(data_vars), dict(attrs)
+        sizes = {k: np.shape(v[1])[0] for k, v in self.coords.items()}
+        for name, (dims, arr, _) in self.data_vars.items():
+            if tuple(sizes[d] for d in dims) != np.shape(arr):
+                raise ValueError(f"{name}: shape {np.shape(arr)} does not match dims {dims} {sizes}")
+        self.sizes = sizes
+
+    def __getitem__(self, name):
+        return (self.data_vars[name] if name in self.data_vars else self.coords[name])[1]
+
+    def __contains__(self, name):
+        return name in self.data_vars or name in self.coords
+
+    def keys(self):
+        return list(self.coords) + list(self.data_vars)
+
+    def to_xarray(self):
         try:
-            import xarray as xr  # noqa: F401
+            import xarray as xr
         except ImportError as e:
-            raise ImportError("Model.to_xr needs xarray, which is not part of the hot-path scope of crt1d_amd") from e
-        raise NotImplementedError("Model.to_xr is not implemented in crt1d_amd (out of the hot-path scope; see DESIGN.md)")
+            raise ImportError("xarray is not installed; use the Dataset returned by Model.to_dataset() directly") from e
+        return xr.Dataset(coords=self.coords, data_vars=self.data_vars, attrs=self.attrs)
 
 
 def run_columns(scheme, columns, **solver_options):

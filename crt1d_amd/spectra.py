@@ -40,3 +40,50 @@ def edges_from_centers_widths(wl, dwl):
     """``wle`` as ``Model._check_inputs`` builds it (``crt1d/model.py:286-287``)."""
     wl, dwl = np.asarray(wl, dtype=float), np.asarray(dwl, dtype=float)
     return np.r_[wl[0] - 0.5 * dwl[0], wl + 0.5 * dwl]
+
+
+def smear_tuv_batched(x, y, bins, *, out=None):
+    """Re-bin ``nspec`` spectra at once on the GPU (``crt_hip_smear_tuv_f64``).
+
+    ``x``: increasing grid ``(nx,)`` shared by all spectra, or ``(nspec, nx)``; ``y``: ``(nspec, nx)``; ``bins``: ``(nbins+1,)``
+    edges.  CUDA float64 tensors (host arrays are copied over).  Returns a ``(nspec, nbins)`` CUDA tensor of in-bin
+    averages, each the reference's ``_smear_tuv_1`` (``crt1d/spectra.py:221-257``) with identical arithmetic."""
+    import ctypes  # noqa: F401
+    import torch
+
+    from . import _lib
+
+    lib = _lib.load()
+    dev = y.device if isinstance(y, torch.Tensor) and y.is_cuda else torch.device("cuda", torch.cuda.current_device())
+
+    def dv(t):
+        return torch.as_tensor(t, dtype=torch.float64).to(dev).contiguous()
+
+    x, y, bins = dv(x), dv(y), dv(bins)
+    if y.ndim != 2 or bins.ndim != 1 or bins.numel() < 1:
+        raise ValueError("y must be (nspec, nx) and bins (nbins+1,)")
+    nspec, nx = y.shape
+    if x.shape == (nx,):
+        x_stride = 0
+    elif x.shape == (nspec, nx):
+        x_stride = nx
+    else:
+        raise ValueError(f"x must be ({nx},) or ({nspec}, {nx}); got {tuple(x.shape)}")
+    nbins = bins.numel() - 1
+    if out is None:
+        out = torch.empty((nspec, nbins), dtype=torch.float64, device=dev)
+    elif out.shape != (nspec, nbins) or out.dtype != torch.float64 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous float64 (nspec, nbins) tensor")
+    if nspec == 0 or nbins == 0:
+        return out
+    with torch.cuda.device(dev):
+        st = lib.crt_hip_smear_tuv_f64(x.data_ptr(), x_stride, nx, y.data_ptr(), nspec, bins.data_ptr(), nbins, out.data_ptr(),
+                                       torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(st, "crt_hip_smear_tuv_f64")
+    return out
+
+
+def smear_tuv(x, y, bins):
+    """Drop-in for ``crt1d.spectra.smear_tuv`` (``crt1d/spectra.py:260-300``): one spectrum, host arrays in and out."""
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    return smear_tuv_batched(x, y[None, :], np.asarray(bins, dtype=np.float64)).cpu().numpy()[0]

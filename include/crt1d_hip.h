@@ -209,6 +209,24 @@ int crt_hip_integrated_f64(int scheme, const crt_columns* cols, const crt_bands*
 int crt_hip_absorb_f64(const crt_columns* cols, const crt_bands* bands, const double* I_dr, const double* I_df_d,
                        const double* I_df_u, double* const* out7, double* laim, double* f_slm, crt_stream_t stream);
 
+/*
+ * Input side, batched.
+ *
+ * crt_hip_smear_tuv_f64 replaces crt1d/spectra.py:260-300 `smear_tuv(x, y, bins)` (per-bin kernel `_smear_tuv_1`,
+ * spectra.py:221-257): out[s][i] = trapezoidal integral of y_s(x) over [bins[i], bins[i+1]] (clipped to the x range)
+ * divided by the bin width.  x: increasing grid, [nx] shared by all spectra (x_stride = 0) or [nspec][x_stride];
+ * y: [nspec][nx]; bins: [nbins + 1]; out: [nspec][nbins].  Same floating-point operations, same order as the reference.
+ *
+ * crt_hip_lai_beta_f64 replaces crt1d/leaf_area.py:42-93 `distribute_lai_beta(h_c, LAI, n, h_min=0.5)` for ncol canopies:
+ * lai, z (and lad unless NULL) are [ncol][nz]; h_c, LAI, h_min are [ncol] (h_min NULL = 0.5 everywhere).  lai is
+ * bit-identical to the reference (numpy.linspace arithmetic); z and lad agree to ~1e-14 (Beta ppf by Newton iteration on
+ * the closed form of I_x(a, 3) instead of scipy's inverse).
+ */
+int crt_hip_smear_tuv_f64(const double* x, int64_t x_stride, int32_t nx, const double* y, int32_t nspec, const double* bins,
+                          int32_t nbins, double* out, crt_stream_t stream);
+int crt_hip_lai_beta_f64(const double* h_c, const double* LAI, const double* h_min, int32_t ncol, int32_t nz, double* lai, double* z,
+                         double* lad, crt_stream_t stream);
+
 /* measurement aid (not for production use): override kernel-selection heuristics, see solve_closed.hip */
 void crt_hip_tune(int key, int value);
 

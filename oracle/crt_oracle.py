@@ -751,3 +751,44 @@ def band_sum(X, wle, band_name="PAR", bounds=None):
     if bounds is None:
         bounds = BAND_DEFNS_UM[band_name]
     return X @ x_frac_in_bounds(wle, bounds)
+
+
+# ---------------------------------------------------------------------------------------------
+# Input side
+def smear_tuv(x, y, bins):
+    """``smear_tuv`` / ``_smear_tuv_1`` (crt1d/spectra.py:221-300): in-bin average of the piecewise-linear ``y(x)``,
+    trapezoid by trapezoid in index order.  Known answers: reference tests/test_spectra.py:38-55 (crt1d.spectra itself
+    cannot be imported here -- it needs xarray -- so those four cases are the pin for this function)."""
+    x, y, bins = np.asarray(x, dtype=float), np.asarray(y, dtype=float), np.asarray(bins, dtype=float)
+    ynew = np.zeros(bins.size - 1)
+    for i in range(bins.size - 1):
+        xl, xu = bins[i], bins[i + 1]
+        area = 0.0
+        for k in range(x.size - 1):
+            if x[k + 1] < xl:  # :240
+                continue
+            if x[k] > xu:  # :242
+                break
+            a1 = max(x[k], xl)
+            a2 = min(x[k + 1], xu)
+            slope = (y[k + 1] - y[k]) / (x[k + 1] - x[k])
+            b1 = y[k] + slope * (a1 - x[k])
+            b2 = y[k] + slope * (a2 - x[k])
+            area = area + (a2 - a1) * (b2 + b1) / 2  # :251
+        ynew[i] = area / (xu - xl)
+    return ynew
+
+
+def distribute_lai_beta(h_c, LAI, n, h_min=0.5):
+    """``distribute_lai_beta`` (crt1d/leaf_area.py:42-93): returns ``(lai, lad, z)``.  Pinned by tests/golden/g8_leaf_area.npz
+    (outputs of the reference's own function)."""
+    from scipy.stats import beta
+
+    d = (h_c - 0.7 * h_c) / h_c
+    b = 3
+    a = -((b - 2) * d + 1) / (d - 1)
+    frac = np.linspace(1.0, 0, n)
+    z = (h_c - h_min) * (1 - beta(a, b).ppf(frac)) + h_min
+    zrel = (z - h_min) / (h_c - h_min)
+    lad = LAI / (h_c - h_min) * beta.pdf(zrel, b, a)
+    return frac * LAI, lad, z

@@ -19,6 +19,7 @@ g3_uniform   12 synthetic columns x 10 bands x 60 levels (equal dLAI), 7 schemes
 g4_ragged    12 synthetic columns x 10 bands x 40 levels, NON-uniform dLAI (exposes the quirks)
 g5_4s_tight  default case, 4s with solve_bvp tol 1e-11 (the reference's stock tol is 1e-6)
 g7_options   mu_s in {0.501, 0.33998}; G_fn in {spherical, horizontal, vertical, ellipsoidal x in {0.5,1,2}, bonan}
+g8_leaf_area reference leaf_area.distribute_lai_beta(h_c, LAI, n, h_min=...) for 8 canopies (lai, lad, z)
 """
 
 import argparse
@@ -234,6 +235,19 @@ def g7(la, lar, sol, out):
     save(out, "g7_options", **arrays)
 
 
+def g8(lar, out):
+    """Leaf-area profiles (leaf_area.py:42-93) -- input side, SURVEY 8(f) rank 4."""
+    cases = [(20.0, 4.0, 60, 0.5), (10.0, 5.0, 20, 0.5), (35.0, 7.5, 100, 2.0), (1.2, 0.8, 5, 0.1), (20.0, 6.0, 61, 0.5),
+             (8.0, 3.0, 2, 0.5), (17.3, 2.2, 33, 0.0), (50.0, 9.9, 200, 5.0)]
+    d = {"h_c": np.array([c[0] for c in cases]), "LAI": np.array([c[1] for c in cases]), "n": np.array([c[2] for c in cases]),
+         "h_min": np.array([c[3] for c in cases])}
+    for i, (h_c, LAI, n, h_min) in enumerate(cases):
+        r = lar.distribute_lai_beta(h_c, LAI, n, h_min=h_min)
+        d[f"c{i}__lai"], d[f"c{i}__lad"], d[f"c{i}__z"] = r.lai, r.lad, r.z
+    np.savez_compressed(out / "g8_leaf_area.npz", meta=np.array(str(META)), **d)
+    print("wrote", out / "g8_leaf_area.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(REPO / "tests" / "golden"))
@@ -273,6 +287,8 @@ def main():
         synth_case(la, sol, out, "g4_ragged", 12, 10, 40, False, ["2s", "4s", "bf", "bl", "g77", "n79", "zq", "zq_pa"], True)
     if want("g7"):
         g7(la, lar, sol, out)
+    if want("g8"):
+        g8(lar, out)
 
 
 if __name__ == "__main__":

@@ -156,3 +156,36 @@ def test_calc_absorption_consistency(oracle):
     top = out["I_dr"][0, -1] + out["I_df_d"][0, -1] - out["I_df_u"][0, -1]
     bot = out["I_dr"][0, 0] + out["I_df_d"][0, 0] - out["I_df_u"][0, 0]
     assert np.max(np.abs(ab["aI"][0].sum(axis=0) - (top - bot))) < 1e-12
+
+
+@pytest.mark.parametrize(
+    "x,bins,expected",
+    [
+        (np.r_[0, 1, 2, 3, 4], (0, 2, 4), [1, 3]),  # equal bin edges in x
+        (np.r_[0, 1, 2, 3, 4], (0, 1, 4), [0.5, 2.5]),  # unequal bin edges in x
+        (np.r_[0, 1, 2, 3, 4], (0, 1, 6), [0.5, 7.5 / (6 - 1)]),  # bin edge beyond x
+        (np.r_[0, 1], (2, 3), [0]),  # single bin fully outside
+    ],
+)
+def test_smear_tuv_known_answers(oracle, x, bins, expected):
+    """The reference's own known answers (tests/test_spectra.py:38-55; y = x is the spectrum)."""
+    np.testing.assert_allclose(oracle.smear_tuv(x, x, bins), expected)
+
+
+def test_smear_tuv_conserves_the_integral(oracle):
+    """Docstring property of smear_tuv (spectra.py:263-266): sum(ynew * dx) == trapezoidal integral over the bins' range."""
+    rng = np.random.default_rng(3)
+    x = np.cumsum(rng.uniform(0.5, 2.0, 400)) * 1e-3 + 0.3
+    y = rng.uniform(0, 1, 400)
+    bins = np.linspace(x[0], x[-1], 38)
+    ynew = oracle.smear_tuv(x, y, bins)
+    np.testing.assert_allclose((ynew * np.diff(bins)).sum(), np.trapezoid(y, x), rtol=1e-12)
+
+
+def test_distribute_lai_beta_vs_reference(oracle):
+    g = load_golden("g8_leaf_area")
+    for i in range(len(g["h_c"])):
+        lai, lad, z = oracle.distribute_lai_beta(float(g["h_c"][i]), float(g["LAI"][i]), int(g["n"][i]), float(g["h_min"][i]))
+        assert np.array_equal(lai, g[f"c{i}__lai"])
+        np.testing.assert_allclose(z, g[f"c{i}__z"], rtol=1e-14)
+        np.testing.assert_allclose(lad, g[f"c{i}__lad"], rtol=1e-12, atol=1e-300)
