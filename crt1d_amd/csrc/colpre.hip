@@ -137,7 +137,8 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   __shared__ double pmb[NQT];   // mu_bar terms, later tau_d(dlai_mean) terms
   __shared__ double pg[NQG];    // G-integral terms
   __shared__ double k9[CRT_NQ_9SKY];
-  __shared__ double sh_kb, sh_dlm;
+  __shared__ double sh_kb, sh_dlm, sh_dl, sh_tdu;
+  __shared__ int sh_unif;
   __shared__ double xis[104];  // zq_pa: cumulative LAI of the computational interfaces
 
   const int c = blockIdx.x;
@@ -221,6 +222,8 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
       rec[15] = 0.0;
       sh_kb = Kb;
       sh_dlm = dlm;
+      sh_dl = dl;
+      sh_unif = unif ? 1 : 0;
     }
   }
   __syncthreads();
@@ -259,6 +262,24 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
     }
   }
 
+  // n79 on an equal-dLAI column (S_UNIF): one layer transmittance pair (tb, td) serves every layer, so tau_d is
+  // evaluated once, one node per thread, instead of once per level; the solve kernels rely on the three layer
+  // vectors (tb, td, 1/(1-td)) being constant when S_UNIF is set (TriN79U, tri_schemes.hpp).
+  const bool n79u = a.scheme == CRT_SCHEME_N79 && sh_unif != 0 && nz >= 3;
+  if (n79u) {
+    const double dl = sh_dl;
+    if (a.tau_d_method == CRT_TAU_D_9SKY) {
+      if (tid == 0) sh_tdu = tau_d_9sky(k9, dl);
+    } else {
+      for (int q = tid; q < NQT; q += K0_BLOCK) pmb[q] = qc.w2sc[q] * exp(-kq[q] * dl);
+      __syncthreads();
+      if (wave == 0) {
+        const double t = wave_sum64(pmb[lane] + (lane < NQT - 64 ? pmb[64 + lane] : 0.0));
+        if (lane == 0) sh_tdu = t;
+      }
+    }
+    __syncthreads();
+  }
   double* v = rec + REC_HDR;
   for (int j = tid; j < nz; j += K0_BLOCK) {
     const double L = lai[j];
@@ -295,8 +316,13 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
         if (j + 1 < nz) {
           const double Ln = lai[j + 1];
           const double dl = L - Ln;                                             // :40
-          tb = exp(-Kb * dl);                                                   // :45
-          td = (a.tau_d_method == CRT_TAU_D_9SKY) ? tau_d_9sky(k9, dl) : tau_d_quad(kq, dl);  // :53
+          if (n79u) {
+            tb = exp(-Kb * sh_dl);
+            td = sh_tdu;
+          } else {
+            tb = exp(-Kb * dl);                                                 // :45
+            td = (a.tau_d_method == CRT_TAU_D_9SKY) ? tau_d_9sky(k9, dl) : tau_d_quad(kq, dl);  // :53
+          }
           fs = exp(-Kb * ((L + Ln) / 2));                                       // :57-58
           isl = 1.0 / (fs * dl);                                                // :154
           ish = 1.0 / ((1.0 - fs) * dl);                                        // :155

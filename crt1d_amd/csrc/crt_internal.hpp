@@ -188,6 +188,11 @@ __device__ inline void store_stream(TIO* p, const double (&v)[VEC]) {
   }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also emits s_waitcnt vmcnt(0), i.e.
+// every wave would drain its outstanding global stores (a full HBM write round trip) twice per tile;
+// the tile protocol only needs the LDS writes/reads of the other waves to have completed.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // 1/x for normal, positive-or-negative x well inside the exponent range: hardware seed + two Newton steps
 // (<= 1 ulp; skips the scaling / fix-up of the IEEE division sequence, ~5 instructions instead of ~10)
 __device__ inline double fast_rcp(double x) {

@@ -505,10 +505,6 @@ struct TileCfg {
   int flags;     // bit0: full __syncthreads() barriers (A/B aid)
 };
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also emits s_waitcnt vmcnt(0), i.e.
-// every wave would drain its outstanding global stores (a full HBM write round trip) twice per tile;
-// the tile protocol only needs the LDS writes/reads of the other waves to have completed.
-__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <class S, typename TIO, int MAXT, bool FUSED>
 __global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {

@@ -13,6 +13,8 @@
 // ORIGINAL even-row equation one level up, which is a contraction (coefficients < 1), so the
 // sweep stays as stable as Thomas and the result differs from it by rounding only.  That halves
 // the footprint: 16 nz bytes per lane -> 2 waves/CU at nz = 60, 1 wave/CU at nz = 100.
+#include <type_traits>
+
 #include "crt_internal.hpp"
 #include "tri_schemes.hpp"
 
@@ -99,13 +101,9 @@ __device__ inline void emit_level(const SolveArgs& a, const double* rec, const I
 // One lane = one (column, band) system; scheme arithmetic in tri_schemes.hpp (shared with the column-tile kernel).
 //   n79: crt1d/solvers/_solve_n79.py:70-155     zq: crt1d/solvers/_solve_zq.py:74-219
 // The pair of the last even row stays in registers; pairs 0 .. K-2 go through EF.
-template <class S, typename TIO, bool USE_LDS, class EF>
-__global__ __launch_bounds__(TB) void k_tri_wave(SolveArgs a, int rec_lds_doubles) {
-  extern __shared__ double lds[];
-  const Item it = locate<TB, 1>(a.ncol, a.nb);
-  const double* rec = stage_records<TB, 1, USE_LDS>(a, it, lds);
-  if (!it.active) return;
-  EF ef(a, it, lds + rec_lds_doubles);
+template <class S, typename TIO, class EF>
+__device__ __forceinline__ void tri_wave_body(const SolveArgs& a, const Item& it, const double* rec, double* lds_ef) {
+  EF ef(a, it, lds_ef);
   const int nz = a.nz, K = S::rows(nz);
   S st;
   st.template init<TIO>(rec, a, it.c, it.b);
@@ -125,6 +123,23 @@ __global__ __launch_bounds__(TB) void k_tri_wave(SolveArgs a, int rec_lds_double
     st.back(k, rec, nz, e, f, v);
     emit_level<S, TIO>(a, rec, it, k, bc, invmu, v);
   }
+}
+
+// a wave can span two columns (nb < 64): the uniform-dLAI object is chosen per lane (divergent only in such waves)
+template <class S, typename TIO, bool USE_LDS, class EF>
+__global__ __launch_bounds__(TB) void k_tri_wave(SolveArgs a, int rec_lds_doubles) {
+  extern __shared__ double lds[];
+  const Item it = locate<TB, 1>(a.ncol, a.nb);
+  const double* rec = stage_records<TB, 1, USE_LDS>(a, it, lds);
+  if (!it.active) return;
+  typedef typename UniformOf<S>::type SU;
+  if constexpr (!std::is_same<S, SU>::value) {
+    if (rec[S_UNIF] != 0.0) {
+      tri_wave_body<SU, TIO, EF>(a, it, rec, lds + rec_lds_doubles);
+      return;
+    }
+  }
+  tri_wave_body<S, TIO, EF>(a, it, rec, lds + rec_lds_doubles);
 }
 
 constexpr size_t MAX_WG_LDS = 160 * 1024;

@@ -18,6 +18,8 @@
 //
 // LDS at nb = 300, nz = 60, M = 12, T = 4: checkpoints 25.6 KB + tile 38.4 KB + record/band constants 5.4 KB
 // = 69 KB -> two workgroups (10 waves) per CU.
+#include <type_traits>
+
 #include "crt_internal.hpp"
 #include "tri_schemes.hpp"
 
@@ -121,18 +123,11 @@ __device__ inline void flush_fused(const SolveArgs& a, const double* rec, const 
 // ------------------------------------------------------------------------------------------
 // The segment loops are fully unrolled: the register-resident pairs be[M], bf[M] need static indices (a runtime-indexed
 // array goes to scratch; VGPR-index mode on vector types works but costs ~40 instructions per level, measured).
-template <class S, typename TIO, int M, int T, int MAXT, bool FUSED>
-__global__ __launch_bounds__(MAXT) void k_tri_tile(SolveArgs a, TriCfg cfg) {
-  static_assert(M % T == 0, "tile height must divide the checkpoint spacing");
-  extern __shared__ double lds[];
+template <class S, typename TIO, int M, int T, bool FUSED>
+__device__ __forceinline__ void tri_tile_body(const SolveArgs& a, const TriCfg& cfg, double* lds) {
   const int nb = a.nb, nz = a.nz;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int c = blockIdx.x;
-  {
-    const double* src = a.ws + (long long)c * a.reclen;
-    for (int i = tid; i < a.reclen; i += nthr) lds[i] = src[i];
-  }
-  __syncthreads();
   const double* rec = lds;
   double* bandc = lds + cfg.off_bc;
   double* ck = lds + cfg.off_ck + tid;       // [nck][2][nthr]
@@ -199,16 +194,38 @@ __global__ __launch_bounds__(MAXT) void k_tri_tile(SolveArgs a, TriCfg cfg) {
       }
       if (i % T == 0) {  // bottom row of a tile (T divides M, segments start at multiples of M)
         if (k <= kend) {
-          __syncthreads();
+          // LDS-only barriers: __syncthreads() would also drain this wave's global stores (vmcnt(0)) and serialise the
+          // recurrence behind the HBM write round trip of the previous tile
+          lds_barrier();
           if constexpr (FUSED)
             flush_fused<S, TIO, T>(a, rec, bandc, tile, c, k, fm, invmu);
           else
             flush_arrays<S, TIO, 0>(a, rec, bandc, tile, tstride, c, k, T, invmu, inv_nb);
-          __syncthreads();
+          lds_barrier();
         }
       }
     }
   }
+}
+
+// S_UNIF columns run the scheme's uniform-dLAI object (UniformOf, tri_schemes.hpp); the flag is per column = per workgroup
+template <class S, typename TIO, int M, int T, int MAXT, bool FUSED>
+__global__ __launch_bounds__(MAXT) void k_tri_tile(SolveArgs a, TriCfg cfg) {
+  static_assert(M % T == 0, "tile height must divide the checkpoint spacing");
+  extern __shared__ double lds[];
+  {
+    const double* src = a.ws + (long long)blockIdx.x * a.reclen;
+    for (int i = threadIdx.x; i < a.reclen; i += blockDim.x) lds[i] = src[i];
+  }
+  __syncthreads();
+  typedef typename UniformOf<S>::type SU;
+  if constexpr (!std::is_same<S, SU>::value) {
+    if (lds[S_UNIF] != 0.0) {
+      tri_tile_body<SU, TIO, M, T, FUSED>(a, cfg, lds);
+      return;
+    }
+  }
+  tri_tile_body<S, TIO, M, T, FUSED>(a, cfg, lds);
 }
 
 template <class S, typename TIO, int M, int T, bool FUSED>
@@ -239,17 +256,11 @@ int launch_mt(const SolveArgs& a, hipStream_t s, int nthr) {
 // ------------------------------------------------------------------------------------------
 // Integrated outputs only (IntArgs, crt_internal.hpp): the same checkpointed sweep, but instead of staging and flushing
 // profiles every level's net flux is reduced across the bands with ngroup wave shuffles.
-template <class S, typename TIO, int M, int MAXT>
-__global__ __launch_bounds__(MAXT) void k_tri_int(SolveArgs a, IntArgs ia, int off_ck, int off_int) {
-  extern __shared__ double lds[];
+template <class S, typename TIO, int M>
+__device__ __forceinline__ void tri_int_body(const SolveArgs& a, const IntArgs& ia, int off_ck, int off_int, double* lds) {
   const int nb = a.nb, nz = a.nz, ng = ia.ngroup;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
   const int c = blockIdx.x;
-  {
-    const double* src = a.ws + (long long)c * a.reclen;
-    for (int i = tid; i < a.reclen; i += nthr) lds[i] = src[i];
-  }
-  __syncthreads();
   const double* rec = lds;
   double* ck = lds + off_ck + tid;  // [nck][2][nthr]
   IntLds L;
@@ -313,6 +324,24 @@ __global__ __launch_bounds__(MAXT) void k_tri_int(SolveArgs a, IntArgs ia, int o
   int_finish<false>(L, ia, nwave, nz, c, rec[S_KB]);
 }
 
+template <class S, typename TIO, int M, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_tri_int(SolveArgs a, IntArgs ia, int off_ck, int off_int) {
+  extern __shared__ double lds[];
+  {
+    const double* src = a.ws + (long long)blockIdx.x * a.reclen;
+    for (int i = threadIdx.x; i < a.reclen; i += blockDim.x) lds[i] = src[i];
+  }
+  __syncthreads();
+  typedef typename UniformOf<S>::type SU;
+  if constexpr (!std::is_same<S, SU>::value) {
+    if (lds[S_UNIF] != 0.0) {
+      tri_int_body<SU, TIO, M>(a, ia, off_ck, off_int, lds);
+      return;
+    }
+  }
+  tri_int_body<S, TIO, M>(a, ia, off_ck, off_int, lds);
+}
+
 template <class S, typename TIO, int M>
 int launch_int_m(const SolveArgs& a, const IntArgs& ia, hipStream_t s, int nthr) {
   const int K = S::rows(a.nz);
@@ -356,6 +385,196 @@ int launch_cfg(const SolveArgs& a, hipStream_t s, int M, int T, int nthr) {
   return CRT_ERR_UNSUPPORTED;
 }
 
+// ------------------------------------------------------------------------------------------
+// Wave-specialised pipeline.  In k_tri_tile every wave of a workgroup alternates between the recurrence and the flush, and
+// because all workgroups run the same schedule the whole chip alternates with them: HBM idles while the recurrences run
+// and the ALUs idle while the store queues drain (measured: time = store time + compute time, for 1 or 2 workgroups
+// per CU alike).  Here the workgroup carries extra "store waves" that do nothing but flush: the compute waves write
+// tile g into one LDS buffer while the store waves stream tile g-1 out of the other, one LDS-only barrier per tile.
+//   barrier #n : compute waves arrive after completing tile n-1, store waves before reading it; a compute wave writes
+//   tile n+1 (same buffer as n-1) only after barrier #n+1, which the store waves reach after their reads of tile n-1.
+struct PipeCfg {
+  int ncomp;     // compute threads (multiple of 64); threads beyond are store threads
+  int nck;
+  int off_bc, off_ck, off_tile;  // LDS offsets in doubles; tile = [2][NST][T][nb]
+};
+
+template <class S, typename TIO, int M, int T>
+__device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
+  const int nb = a.nb, nz = a.nz;
+  const int tid = threadIdx.x, nthr = cfg.ncomp;
+  const int c = blockIdx.x;
+  const double* rec = lds;
+  double* bandc = lds + cfg.off_bc;
+  double* ck = lds + cfg.off_ck + tid;  // [nck][2][ncomp]
+  double* tile = lds + cfg.off_tile;
+  const int tstride = T * nb, bstride = S::NST * tstride;
+  const bool active = tid < nb;
+  const int b = active ? tid : 0;
+  S st;
+  st.template init<TIO>(rec, a, c, b);
+  if (active) bandc[b] = st.band_const();
+  const int K = S::rows(nz);
+  double e, f;
+  st.first(rec, nz, e, f);
+  ck[0] = e;
+  ck[nthr] = f;
+  for (int k = 0; k + 1 < K; ++k) {
+    st.advance(k, rec, nz, e, f);
+    if ((k + 1) % M == 0) {
+      const int sidx = (k + 1) / M;
+      ck[(2 * sidx) * nthr] = e;
+      ck[(2 * sidx + 1) * nthr] = f;
+    }
+  }
+  int buf = 0;
+  for (int seg = (K - 1) / M; seg >= 0; --seg) {
+    const int k0 = seg * M;
+    const int kend = min(k0 + M - 1, K - 1);
+    double be[M], bf[M];
+    be[0] = ck[(2 * seg) * nthr];
+    bf[0] = ck[(2 * seg + 1) * nthr];
+#pragma unroll
+    for (int i = 1; i < M; ++i) {
+      be[i] = be[i - 1];
+      bf[i] = bf[i - 1];
+      if (k0 + i <= kend) st.advance(k0 + i - 1, rec, nz, be[i], bf[i]);
+    }
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+      const int k = k0 + i;
+      if (k <= kend) {
+        double o[S::NST];
+        if (k == K - 1)
+          st.top(rec, nz, be[i], bf[i], o);
+        else
+          st.back(k, rec, nz, be[i], bf[i], o);
+        if (active) {
+#pragma unroll
+          for (int q = 0; q < S::NST; ++q) tile[buf * bstride + q * tstride + (i % T) * nb + b] = o[q];
+        }
+        if (i % T == 0) {  // tile complete: hand it to the store waves
+          lds_barrier();
+          buf ^= 1;
+        }
+      }
+    }
+  }
+}
+
+template <class S, typename TIO, int M, int T>
+__device__ __forceinline__ void tri_pipe_store(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
+  const int nb2 = a.nb >> 1, nz = a.nz;
+  const int c = blockIdx.x;
+  const int sid = threadIdx.x - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
+  const double* rec = lds;
+  const d2* bandc2 = reinterpret_cast<const d2*>(lds + cfg.off_bc);
+  const d2* tile2 = reinterpret_cast<const d2*>(lds + cfg.off_tile);
+  const double invmu = rec[S_INVMU];
+  const int K = S::rows(nz);
+  // thread -> (row, band pair) walk over the T x nb2 pairs of a tile: consecutive threads, consecutive 16-B words
+  const int dt = nst / nb2, dp = nst - dt * nb2;
+  const int t0 = sid / nb2, p0 = sid - t0 * nb2;
+  int buf = 0;
+  for (int seg = (K - 1) / M; seg >= 0; --seg) {
+    const int k0 = seg * M;
+    const int kend = min(k0 + M - 1, K - 1);
+    for (int i = M - T; i >= 0; i -= T) {
+      const int k = k0 + i;
+      if (k > kend) continue;
+      lds_barrier();  // tile `buf` is complete
+      const d2* tb = tile2 + (size_t)buf * (S::NST * T * nb2);
+      const int jmax = min(kend, nz - 1);
+      int t = t0, p = p0;
+      while (t < T) {
+        const int j = k + t;
+        if (j <= jmax) {
+          d2 st[S::NST], o[S::NOUT];
+#pragma unroll
+          for (int q = 0; q < S::NST; ++q) st[q] = tb[(q * T + t) * nb2 + p];
+          S::emit(rec, nz, j, bandc2[p], invmu, st, o);
+#pragma unroll
+          for (int r = 0; r < S::NOUT; ++r) {
+            const int rows = S::out_rows(r, nz);
+            if (j < rows) {
+              typedef TIO vt __attribute__((ext_vector_type(2)));
+              vt v;
+              v.x = (TIO)o[r].x;
+              v.y = (TIO)o[r].y;
+              reinterpret_cast<vt*>(a.o[r])[((long long)c * rows + j) * nb2 + p] = v;
+            }
+          }
+        }
+        p += dp;
+        t += dt;
+        if (p >= nb2) {
+          p -= nb2;
+          ++t;
+        }
+      }
+      buf ^= 1;
+    }
+  }
+}
+
+template <class S, typename TIO, int M, int T, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_tri_pipe(SolveArgs a, PipeCfg cfg) {
+  static_assert(M % T == 0, "tile height must divide the checkpoint spacing");
+  extern __shared__ double lds[];
+  {
+    const double* src = a.ws + (long long)blockIdx.x * a.reclen;
+    for (int i = threadIdx.x; i < a.reclen; i += blockDim.x) lds[i] = src[i];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x >= cfg.ncomp) {
+    tri_pipe_store<S, TIO, M, T>(a, cfg, lds);
+    return;
+  }
+  typedef typename UniformOf<S>::type SU;
+  if constexpr (!std::is_same<S, SU>::value) {
+    if (lds[S_UNIF] != 0.0) {
+      tri_pipe_compute<SU, TIO, M, T>(a, cfg, lds);
+      return;
+    }
+  }
+  tri_pipe_compute<S, TIO, M, T>(a, cfg, lds);
+}
+
+// returns CRT_ERR_UNSUPPORTED when the shape does not fit (caller falls back to k_tri_tile)
+template <class S, typename TIO, int M, int T>
+int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves) {
+  const int ncomp = ((a.nb + 63) / 64) * 64;
+  const int nthr = ncomp + 64 * nstore_waves;
+  if (nthr > 1024) return CRT_ERR_UNSUPPORTED;
+  const int K = S::rows(a.nz);
+  PipeCfg cfg;
+  cfg.ncomp = ncomp;
+  cfg.nck = (K - 1) / M + 1;
+  cfg.off_bc = (a.reclen + 1) & ~1;
+  cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
+  cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
+  const size_t sh = ((size_t)cfg.off_tile + (size_t)2 * S::NST * T * a.nb) * sizeof(double);
+  if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
+  auto go = [&](auto kern) {
+    if (sh > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+      return (int)CRT_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, cfg);
+    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+  };
+  if (nthr <= 512) return go(k_tri_pipe<S, TIO, M, T, 512>);
+  return go(k_tri_pipe<S, TIO, M, T, 1024>);
+}
+
+template <class S, typename TIO>
+int launch_pipe(const SolveArgs& a, hipStream_t s, int M, int T, int nsw) {
+  if (M == 8 && T == 4) return launch_pipe_mt<S, TIO, 8, 4>(a, s, nsw);
+  if (M == 12 && T == 4) return launch_pipe_mt<S, TIO, 12, 4>(a, s, nsw);
+  if (M == 16 && T == 4) return launch_pipe_mt<S, TIO, 16, 4>(a, s, nsw);
+  if (M == 16 && T == 8) return launch_pipe_mt<S, TIO, 16, 8>(a, s, nsw);
+  return CRT_ERR_UNSUPPORTED;
+}
+
 template <class S, typename TIO>
 int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 64) {
   done = false;
@@ -390,6 +609,28 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 64
   bool fused = (a.nb % 2 == 0);
   for (int i = 0; i < S::NOUT && fused; ++i)
     if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) fused = false;
+  if (fused && g_tri_tune[2] != 1) {  // wave-specialised pipeline first (tune key 10 = 1 disables, key 11 = store waves)
+    // Measured on MI355X at 1e4 x 300 x 60 (tools/ab_tri.py, fill probe 6.8 TB/s), best k_tri_tile config -> pipeline:
+    //   n79: 1.615 ms (M12/T12) -> 1.522 ms (M12/T4, 4 store waves; 3 waves 1.56, 2 waves 1.59)
+    //   zq : 1.797 ms (M16/T8)  -> 1.763 ms (M8/T4, 3 store waves)
+    int nsw = g_tri_tune[3] > 0 ? g_tri_tune[3] : 4;
+    if (nthr + 64 * nsw > 1024) nsw = (1024 - nthr) / 64;
+    int st = CRT_ERR_UNSUPPORTED;
+    if (nsw >= 1) {
+      if (g_tri_tune[0] > 0) {
+        st = launch_pipe<S, TIO>(a, s, M, T, nsw);
+      } else {
+        const int pp_n79[3][2] = {{12, 4}, {16, 4}, {8, 4}};
+        const int pp_zq[3][2] = {{8, 4}, {12, 4}, {16, 4}};
+        const int (*pp)[2] = S::NOUT == 6 ? pp_n79 : pp_zq;
+        for (int i = 0; i < 3 && st == CRT_ERR_UNSUPPORTED; ++i) st = launch_pipe<S, TIO>(a, s, pp[i][0], pp[i][1], nsw);
+      }
+    }
+    if (st != CRT_ERR_UNSUPPORTED) {
+      done = st == CRT_OK;
+      return st;
+    }
+  }
   const int st = fused ? launch_cfg<S, TIO, true>(a, s, M, T, nthr) : launch_cfg<S, TIO, false>(a, s, M, T, nthr);
   if (st == CRT_ERR_UNSUPPORTED) return CRT_OK;
   done = st == CRT_OK;

@@ -7,13 +7,28 @@ from crt1d_amd import _lib, batched, synth
 scheme = sys.argv[1] if len(sys.argv) > 1 else "n79"
 nz = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 ncol, nb = 10000, 300
-d = synth.make_columns(ncol, nb, nz)
+ragged = len(sys.argv) > 3 and sys.argv[3] == "ragged"
+d = synth.make_columns(ncol, nb, nz, uniform_dlai=not ragged)
 cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
 plan = batched.Plan(scheme, cols, bands)
 lib = _lib.load()
-variants = {"auto": (0, 0), "M8 T4": (8, 4), "M12 T4": (12, 4), "M16 T4": (16, 4), "M8 T8": (8, 8), "M16 T8": (16, 8), "M12 T12": (12, 12), "M16 T8b": (16, 8),
-            "M16 T16": (16, 16), "per-wave": None}
+# (M, T, pipe?, store waves)
+variants = {"tile M12 T4": (12, 4, 0, 0), "tile M8 T8": (8, 8, 0, 0), "tile M12 T12": (12, 12, 0, 0), "tile M16 T8": (16, 8, 0, 0),
+            "pipe M12 T4 s3": (12, 4, 1, 3), "pipe M12 T4 s2": (12, 4, 1, 2), "pipe M12 T4 s4": (12, 4, 1, 4), "pipe M8 T4 s3": (8, 4, 1, 3),
+            "pipe M16 T4 s3": (16, 4, 1, 3), "pipe M16 T8 s3": (16, 8, 1, 3), "per-wave": None}
 res = {k: [] for k in variants}
+plan(); torch.cuda.synchronize()  # K0 once: the timed launches below skip the precompute and reuse this workspace
+buf = torch.empty(2 * 10**9 // 8, dtype=torch.float64, device="cuda")
+def fill_rate():
+    st_ = torch.cuda.current_stream().cuda_stream
+    lib.crt_hip_probe_fill_f64(buf.data_ptr(), buf.numel(), 1.0, st_); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        lib.crt_hip_probe_fill_f64(buf.data_ptr(), buf.numel(), 1.0, st_)
+    b.record(); torch.cuda.synchronize()
+    return buf.numel() * 8 * 5 / (a.elapsed_time(b) * 1e-3) / 1e9
+print(f"fill probe {fill_rate():.0f} GB/s")
 st = torch.cuda.current_stream()
 for rnd in range(5):
     for name, mt in variants.items():
@@ -21,7 +36,7 @@ for rnd in range(5):
         if mt is None:
             flags |= _lib.FLAG_DIRECT_STORES
         else:
-            lib.crt_hip_tune(8, mt[0]); lib.crt_hip_tune(9, mt[1])
+            lib.crt_hip_tune(8, mt[0]); lib.crt_hip_tune(9, mt[1]); lib.crt_hip_tune(10, 0 if mt[2] else 1); lib.crt_hip_tune(11, mt[3])
         plan(flags=flags); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
@@ -31,4 +46,4 @@ for rnd in range(5):
         res[name].append(e0.elapsed_time(e1) / 5)
 for name, v in res.items():
     v = sorted(v)
-    print(f"{scheme} nz={nz} {name:10s} median {v[len(v)//2]:.4f} ms  min {v[0]:.4f} ms")
+    print(f"{scheme} nz={nz} ragged={ragged} {name:16s} median {v[len(v)//2]:.4f} ms  min {v[0]:.4f} ms")
