@@ -37,7 +37,7 @@ N_IO = {  # scheme: (n_in, n_full, n_mid)
     "zq_pa": (5, 4, 0),
 }
 # dominant kernel per scheme as rocprofv3 names it (template arguments abbreviated)
-KERNEL_NAMES = {"2s": "k_tile<Sch2s>", "4s": "k_tile<Sch4s>", "bl": "k_tile<SchBl>", "g77": "k_tile<SchG77<false>>",
+KERNEL_NAMES = {"2s": "k_pipe<Sch2s>", "4s": "k_pipe<Sch4s>", "bl": "k_pipe<SchBl>", "g77": "k_tile<SchG77<false>>",
                 "bf": "k_tile<SchG77<true>>", "n79": "k_tri_pipe<TriN79>", "zq": "k_tri_pipe<TriZq>", "zq_pa": "k_tri_pipe<TriZqPa> (+ k_zqpa_interp)"}
 
 

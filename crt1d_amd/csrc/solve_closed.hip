@@ -596,6 +596,86 @@ __global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_pipe: k_tile's fused case (one column per workgroup) with the roles separated.  In k_tile all waves alternate between
+// the level arithmetic and the flush, and every workgroup on the chip follows the same schedule, so the store queues run
+// dry while the level arithmetic executes (time ~ store time + compute time).  Here `ncomp` compute threads (one per band)
+// fill tile g in one LDS buffer while the remaining "store waves" stream tile g-1 out of the other buffer;
+// one LDS-only barrier per tile (protocol: see k_tri_pipe in solve_tridiag_tile.hip).
+struct PipeTileCfg {
+  int ncomp;    // compute threads (multiple of 64)
+  int T;        // levels per tile
+  int rec_dbl;  // doubles reserved for the staged column record
+};
+
+template <class S, typename TIO, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
+  constexpr int VW = 16 / (int)sizeof(TIO);
+  typedef TIO vt __attribute__((ext_vector_type(VW)));
+  extern __shared__ double lds[];
+  const int nb = a.nb, nz = a.nz, T = cfg.T;
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x;
+  {
+    const double* src = a.ws + (long long)c * a.reclen;
+    for (int i = tid; i < a.reclen; i += blockDim.x) lds[i] = src[i];
+  }
+  __syncthreads();
+  const double* rec = lds;
+  TIO* tile = reinterpret_cast<TIO*>(lds + cfg.rec_dbl);  // [2][NARR][T][nb]
+  const int colrun = T * nb, bufrun = S::NARR * colrun;
+  if (tid < cfg.ncomp) {
+    // ---- compute role ----
+    const bool active = tid < nb;
+    const int b = active ? tid : 0;
+    S st;
+    st.init(rec, load_band<TIO>(a, c, b, S::SOIL), a);
+    int buf = 0;
+    for (int j0 = 0; j0 < nz; j0 += T) {
+      const int Tc = min(T, nz - j0);
+      TIO* tl = tile + buf * bufrun + b;
+      for (int t = 0; t < Tc; ++t) {
+        double val[S::NARR];
+        st.level(j0 + t, rec, nz, val);
+        if (active) {
+#pragma unroll
+          for (int k = 0; k < S::NARR; ++k) tl[k * colrun + t * nb] = (TIO)val[k];
+        }
+      }
+      lds_barrier();  // tile complete: hand it to the store waves
+      buf ^= 1;
+    }
+  } else {
+    // ---- store role: thread -> (row, 16-B vector) walk over the T x nbv vectors of a tile ----
+    const int nbv = nb / VW;
+    const int sid = tid - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
+    const int dt = nst / nbv, dp = nst - dt * nbv;
+    const int t0 = sid / nbv, p0 = sid - t0 * nbv;
+    int buf = 0;
+    for (int j0 = 0; j0 < nz; j0 += T) {
+      const int Tc = min(T, nz - j0);
+      lds_barrier();  // tile `buf` is complete
+      const vt* tv = reinterpret_cast<const vt*>(tile + buf * bufrun);
+      int t = t0, p = p0;
+      while (t < Tc) {
+        const long long go = ((long long)c * nz + j0 + t) * nbv + p;
+        vt v[S::NARR];
+#pragma unroll
+        for (int k = 0; k < S::NARR; ++k) v[k] = tv[(k * colrun + t * nb) / VW + p];
+#pragma unroll
+        for (int k = 0; k < S::NARR; ++k) reinterpret_cast<vt*>(a.o[k])[go] = v[k];
+        p += dp;
+        t += dt;
+        if (p >= nbv) {
+          p -= nbv;
+          ++t;
+        }
+      }
+      buf ^= 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 constexpr int MAX_DIRECT_LDS = 64 * 1024;
 // tunables (crt_hip_tune): [0] LDS bytes a tile may take per workgroup, [1] force T (0 = automatic),
 // [2] TileCfg.flags (bit0: __syncthreads barriers, bit1: generic instead of fused flush).  Measured on MI355X, 2s at 1e4 x 300 x 60 (tools/ab_tile.py, interleaved rounds):
@@ -638,6 +718,33 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
   for (int i = 0; i < S::NARR && fused; ++i)
     if (reinterpret_cast<uintptr_t>(a.o[i]) & 15) fused = false;
   const int grid = (a.ncol + CB - 1) / CB;
+  if (fused && !(g_tune[2] & 4)) {  // wave-specialised pipeline (tune [2] bit2 disables, [3] = store waves, [4] = its T)
+    int nsw = g_tune[3] > 0 ? g_tune[3] : 3;
+    if (nthr + 64 * nsw > 1024) nsw = (1024 - nthr) / 64;
+    // two buffers of the longest line-aligned run that keeps two workgroups per CU
+    int Tp = Ta;
+    while (2 * per_level * (Tp + Ta) <= target && Tp + Ta <= a.nz) Tp += Ta;
+    if (g_tune[4] > 0) Tp = g_tune[4];
+    if (Tp > a.nz) Tp = a.nz;
+    PipeTileCfg pc;
+    pc.ncomp = nthr;
+    pc.T = Tp;
+    pc.rec_dbl = (a.reclen + 1) & ~1;
+    const size_t psh = pc.rec_dbl * sizeof(double) + 2 * per_level * Tp;
+    if (nsw >= 1 && psh <= 160 * 1024 && (2 * per_level * Ta <= target || g_tune[4] > 0)) {
+      const int pthr = nthr + 64 * nsw;
+      auto gop = [&](auto kern) {
+        if (psh > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh) != hipSuccess)
+          return (int)CRT_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(pthr), psh, s, a, pc);
+        return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+      };
+      const int st = pthr <= 512 ? gop(k_pipe<S, TIO, 512>) : gop(k_pipe<S, TIO, 1024>);
+      done = st == CRT_OK;
+      return st;
+    }
+  }
   auto go = [&](auto kern) {
     if (sh > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)

@@ -10,16 +10,32 @@ d = synth.make_columns(ncol, nb, nz)
 cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
 plan = batched.Plan(scheme, cols, bands)
 lib = _lib.load()
+# tune keys: 0 = LDS target bytes, 1 = force T (k_tile), 2 = flags (bit1 generic flush, bit2 no pipeline), 3 = store waves, 4 = pipeline T
 variants = {
-    "tile T=8 fused": {0: 160 * 1024, 1: 8, 2: 0},
-    "tile T=8 generic flush": {0: 160 * 1024, 1: 8, 2: 2},
-    "tile T=4 fused": {0: 40960, 1: 4, 2: 0},
-    "tile T=4 generic flush": {0: 40960, 1: 4, 2: 2},
-    "tile T=12 fused": {0: 160 * 1024, 1: 12, 2: 0},
-    "tile T=16 fused": {0: 160 * 1024, 1: 16, 2: 0},
+    "tile T=8 fused": {0: 78 * 1024, 1: 8, 2: 4, 3: 0, 4: 0},
+    "tile T=4 fused": {0: 78 * 1024, 1: 4, 2: 4, 3: 0, 4: 0},
+    "tile T=12 fused": {0: 160 * 1024, 1: 12, 2: 4, 3: 0, 4: 0},
+    "pipe T=4 s3": {0: 78 * 1024, 1: 0, 2: 0, 3: 3, 4: 4},
+    "pipe T=4 s2": {0: 78 * 1024, 1: 0, 2: 0, 3: 2, 4: 4},
+    "pipe T=4 s4": {0: 78 * 1024, 1: 0, 2: 0, 3: 4, 4: 4},
+    "pipe T=4 s1": {0: 78 * 1024, 1: 0, 2: 0, 3: 1, 4: 4},
+    "pipe T=8 s3": {0: 78 * 1024, 1: 0, 2: 0, 3: 3, 4: 8},
+    "pipe T=2 s3": {0: 78 * 1024, 1: 0, 2: 0, 3: 3, 4: 2},
     "direct": None,
 }
 res = {k: [] for k in variants}
+plan(); torch.cuda.synchronize()  # K0 once: the timed launches below skip the precompute and reuse this workspace
+buf = torch.empty(2 * 10**9 // 8, dtype=torch.float64, device="cuda")
+def fill_rate():
+    st_ = torch.cuda.current_stream().cuda_stream
+    lib.crt_hip_probe_fill_f64(buf.data_ptr(), buf.numel(), 1.0, st_); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        lib.crt_hip_probe_fill_f64(buf.data_ptr(), buf.numel(), 1.0, st_)
+    b.record(); torch.cuda.synchronize()
+    return buf.numel() * 8 * 5 / (a.elapsed_time(b) * 1e-3) / 1e9
+print(f"fill probe {fill_rate():.0f} GB/s")
 st = torch.cuda.current_stream()
 for rnd in range(6):
     for name, tune in variants.items():
