@@ -399,7 +399,7 @@ struct PipeCfg {
   int off_bc, off_ck, off_tile;  // LDS offsets in doubles; tile = [2][NST][T][nb]
 };
 
-template <class S, typename TIO, int M, int T>
+template <class S, typename TIO, int M, int T, int RS>
 __device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
   const int nb = a.nb, nz = a.nz;
   const int tid = threadIdx.x, nthr = cfg.ncomp;
@@ -455,7 +455,81 @@ __device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeC
         }
         if (i % T == 0) {  // tile complete: hand it to the store waves
           lds_barrier();
-          buf ^= 1;
+          if constexpr (RS > 0)
+            lds_barrier();  // single buffer: wait until the store waves hold the tile in registers
+          else
+            buf ^= 1;
+        }
+      }
+    }
+  }
+}
+
+// RS > 0: ONE LDS tile buffer; the store waves pull the finished tile into registers (RS band pairs x NST staged values per
+// thread), release the buffer with a second barrier and only then issue the stores, so the registers of the store waves
+// play the part of the second buffer.  Halves the tile's LDS -> two workgroups per CU, whose forward sweeps (no stores yet)
+// hide behind each other's flushes.
+template <class S, typename TIO, int M, int T, int RS>
+__device__ __forceinline__ void tri_pipe_store_rs(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
+  const int nb2 = a.nb >> 1, nz = a.nz;
+  const int c = blockIdx.x;
+  const int sid = threadIdx.x - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
+  const double* rec = lds;
+  const d2* bandc2 = reinterpret_cast<const d2*>(lds + cfg.off_bc);
+  const d2* tb = reinterpret_cast<const d2*>(lds + cfg.off_tile);
+  const double invmu = rec[S_INVMU];
+  const int K = S::rows(nz);
+  const int dt = nst / nb2, dp = nst - dt * nb2;
+  const int t0 = sid / nb2, p0 = sid - t0 * nb2;
+  for (int seg = (K - 1) / M; seg >= 0; --seg) {
+    const int k0 = seg * M;
+    const int kend = min(k0 + M - 1, K - 1);
+    for (int i = M - T; i >= 0; i -= T) {
+      const int k = k0 + i;
+      if (k > kend) continue;
+      const int jmax = min(kend, nz - 1);
+      d2 v[RS][S::NST];
+      int tt[RS], pp[RS];
+      lds_barrier();  // tile complete
+      {
+        int t = t0, p = p0;
+#pragma unroll
+        for (int it = 0; it < RS; ++it) {
+          tt[it] = t;
+          pp[it] = p;
+          if (t < T) {
+#pragma unroll
+            for (int q = 0; q < S::NST; ++q) v[it][q] = tb[(q * T + t) * nb2 + p];
+          }
+          p += dp;
+          t += dt;
+          if (p >= nb2) {
+            p -= nb2;
+            ++t;
+          }
+        }
+      }
+      lds_barrier();  // values are in registers (lgkmcnt(0) inside): the compute waves may overwrite the tile
+#pragma unroll
+      for (int it = 0; it < RS; ++it) {
+        __builtin_amdgcn_sched_barrier(0);  // one pair at a time: keeps the emit temporaries of the RS pairs from being live together
+        const int j = k + tt[it];
+        if (tt[it] < T && j <= jmax) {
+          d2 o[S::NOUT];
+          S::emit(rec, nz, j, bandc2[pp[it]], invmu, v[it], o);
+#pragma unroll
+          for (int r = 0; r < S::NOUT; ++r) {
+            const int rows = S::out_rows(r, nz);
+            if (j < rows) {
+              typedef TIO vt __attribute__((ext_vector_type(2)));
+              vt w;
+              w.x = (TIO)o[r].x;
+              w.y = (TIO)o[r].y;
+              // wave-uniform column base (scalar registers) + one 32-bit lane offset shared by all arrays
+              vt* colbase = reinterpret_cast<vt*>(a.o[r]) + (long long)c * rows * nb2;
+              colbase[(unsigned)(j * nb2 + pp[it])] = w;
+            }
+          }
         }
       }
     }
@@ -501,7 +575,8 @@ __device__ __forceinline__ void tri_pipe_store(const SolveArgs& a, const PipeCfg
               vt v;
               v.x = (TIO)o[r].x;
               v.y = (TIO)o[r].y;
-              reinterpret_cast<vt*>(a.o[r])[((long long)c * rows + j) * nb2 + p] = v;
+              vt* colbase = reinterpret_cast<vt*>(a.o[r]) + (long long)c * rows * nb2;
+              colbase[(unsigned)(j * nb2 + p)] = v;
             }
           }
         }
@@ -517,7 +592,7 @@ __device__ __forceinline__ void tri_pipe_store(const SolveArgs& a, const PipeCfg
   }
 }
 
-template <class S, typename TIO, int M, int T, int MAXT>
+template <class S, typename TIO, int M, int T, int MAXT, int RS>
 __global__ __launch_bounds__(MAXT) void k_tri_pipe(SolveArgs a, PipeCfg cfg) {
   static_assert(M % T == 0, "tile height must divide the checkpoint spacing");
   extern __shared__ double lds[];
@@ -527,25 +602,31 @@ __global__ __launch_bounds__(MAXT) void k_tri_pipe(SolveArgs a, PipeCfg cfg) {
   }
   __syncthreads();
   if ((int)threadIdx.x >= cfg.ncomp) {
-    tri_pipe_store<S, TIO, M, T>(a, cfg, lds);
+    if constexpr (RS > 0)
+      tri_pipe_store_rs<S, TIO, M, T, RS>(a, cfg, lds);
+    else
+      tri_pipe_store<S, TIO, M, T>(a, cfg, lds);
     return;
   }
   typedef typename UniformOf<S>::type SU;
   if constexpr (!std::is_same<S, SU>::value) {
     if (lds[S_UNIF] != 0.0) {
-      tri_pipe_compute<SU, TIO, M, T>(a, cfg, lds);
+      tri_pipe_compute<SU, TIO, M, T, RS>(a, cfg, lds);
       return;
     }
   }
-  tri_pipe_compute<S, TIO, M, T>(a, cfg, lds);
+  tri_pipe_compute<S, TIO, M, T, RS>(a, cfg, lds);
 }
 
 // returns CRT_ERR_UNSUPPORTED when the shape does not fit (caller falls back to k_tri_tile)
+constexpr int PIPE_RS = 4;  // band pairs a store thread holds in the register-staged variant
+
 template <class S, typename TIO, int M, int T>
-int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves) {
+int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves, bool regstage) {
   const int ncomp = ((a.nb + 63) / 64) * 64;
   const int nthr = ncomp + 64 * nstore_waves;
   if (nthr > 1024) return CRT_ERR_UNSUPPORTED;
+  if (regstage && T * (a.nb / 2) > PIPE_RS * 64 * nstore_waves) return CRT_ERR_UNSUPPORTED;
   const int K = S::rows(a.nz);
   PipeCfg cfg;
   cfg.ncomp = ncomp;
@@ -553,8 +634,8 @@ int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves) {
   cfg.off_bc = (a.reclen + 1) & ~1;
   cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
   cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
-  const size_t sh = ((size_t)cfg.off_tile + (size_t)2 * S::NST * T * a.nb) * sizeof(double);
-  if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
+  const size_t sh = ((size_t)cfg.off_tile + (size_t)(regstage ? 1 : 2) * S::NST * T * a.nb) * sizeof(double);
+  if (sh > (regstage ? MAX_WG_LDS / 2 : MAX_WG_LDS)) return CRT_ERR_UNSUPPORTED;  // register staging only pays with 2 WG/CU
   auto go = [&](auto kern) {
     if (sh > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
@@ -562,16 +643,16 @@ int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves) {
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, cfg);
     return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
   };
-  if (nthr <= 512) return go(k_tri_pipe<S, TIO, M, T, 512>);
-  return go(k_tri_pipe<S, TIO, M, T, 1024>);
+  if (regstage) return nthr <= 512 ? go(k_tri_pipe<S, TIO, M, T, 512, PIPE_RS>) : go(k_tri_pipe<S, TIO, M, T, 1024, PIPE_RS>);
+  return nthr <= 512 ? go(k_tri_pipe<S, TIO, M, T, 512, 0>) : go(k_tri_pipe<S, TIO, M, T, 1024, 0>);
 }
 
 template <class S, typename TIO>
-int launch_pipe(const SolveArgs& a, hipStream_t s, int M, int T, int nsw) {
-  if (M == 8 && T == 4) return launch_pipe_mt<S, TIO, 8, 4>(a, s, nsw);
-  if (M == 12 && T == 4) return launch_pipe_mt<S, TIO, 12, 4>(a, s, nsw);
-  if (M == 16 && T == 4) return launch_pipe_mt<S, TIO, 16, 4>(a, s, nsw);
-  if (M == 16 && T == 8) return launch_pipe_mt<S, TIO, 16, 8>(a, s, nsw);
+int launch_pipe(const SolveArgs& a, hipStream_t s, int M, int T, int nsw, bool regstage) {
+  if (M == 8 && T == 4) return launch_pipe_mt<S, TIO, 8, 4>(a, s, nsw, regstage);
+  if (M == 12 && T == 4) return launch_pipe_mt<S, TIO, 12, 4>(a, s, nsw, regstage);
+  if (M == 16 && T == 4) return launch_pipe_mt<S, TIO, 16, 4>(a, s, nsw, regstage);
+  if (M == 16 && T == 8) return launch_pipe_mt<S, TIO, 16, 8>(a, s, nsw, regstage);
   return CRT_ERR_UNSUPPORTED;
 }
 
@@ -610,20 +691,28 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 64
   for (int i = 0; i < S::NOUT && fused; ++i)
     if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) fused = false;
   if (fused && g_tri_tune[2] != 1) {  // wave-specialised pipeline first (tune key 10 = 1 disables, key 11 = store waves)
-    // Measured on MI355X at 1e4 x 300 x 60 (tools/ab_tri.py, fill probe 6.8 TB/s), best k_tri_tile config -> pipeline:
-    //   n79: 1.615 ms (M12/T12) -> 1.522 ms (M12/T4, 4 store waves; 3 waves 1.56, 2 waves 1.59)
-    //   zq : 1.797 ms (M16/T8)  -> 1.763 ms (M8/T4, 3 store waves)
+    // Measured on MI355X at 1e4 x 300 (tools/ab_tri.py, profiles/r01/ab_tri_pipe_*.txt; fill probe 6.3-6.8 TB/s):
+    //                best k_tri_tile -> double-buffer pipeline (1 WG/CU) -> register-staged pipeline (2 WG/CU)
+    //   n79 nz=60 :  1.649 ms        -> 1.522 (M12/T4, 4 store waves)    -> 1.384 (M12/T4, 3 store waves) = 0.93 of the fill rate
+    //   zq  nz=60 :  1.852           -> 1.771 (M8/T4, 3)                 -> 1.607 (M12/T4, 3)             = 0.95
+    //   zq  nz=100:  3.115           -> 2.902 (M16/T4, 4)                -> 2.857 (M16/T4, 3)             = 0.93
     int nsw = g_tri_tune[3] > 0 ? g_tri_tune[3] : 4;
     if (nthr + 64 * nsw > 1024) nsw = (1024 - nthr) / 64;
     int st = CRT_ERR_UNSUPPORTED;
     if (nsw >= 1) {
+      // tune key 10: 0 = automatic, 1 = no pipeline, 2 = double-buffer pipeline only, 3 = register-staged only
+      const bool try_rs = g_tri_tune[2] != 2, try_db = g_tri_tune[2] != 3;
+      // register-staged: 5 compute + 3 store waves = 8 waves per workgroup, two workgroups fill the 16 wave slots of a CU at <= 128 VGPRs
+      const int nsw_rs = g_tri_tune[3] > 0 ? nsw : min(nsw, 3);
       if (g_tri_tune[0] > 0) {
-        st = launch_pipe<S, TIO>(a, s, M, T, nsw);
+        if (try_rs) st = launch_pipe<S, TIO>(a, s, M, T, nsw_rs, true);
+        if (st == CRT_ERR_UNSUPPORTED && try_db) st = launch_pipe<S, TIO>(a, s, M, T, nsw, false);
       } else {
         const int pp_n79[3][2] = {{12, 4}, {16, 4}, {8, 4}};
         const int pp_zq[3][2] = {{8, 4}, {12, 4}, {16, 4}};
         const int (*pp)[2] = S::NOUT == 6 ? pp_n79 : pp_zq;
-        for (int i = 0; i < 3 && st == CRT_ERR_UNSUPPORTED; ++i) st = launch_pipe<S, TIO>(a, s, pp[i][0], pp[i][1], nsw);
+        for (int i = 0; i < 3 && st == CRT_ERR_UNSUPPORTED && try_rs; ++i) st = launch_pipe<S, TIO>(a, s, pp[i][0], pp[i][1], nsw_rs, true);
+        for (int i = 0; i < 3 && st == CRT_ERR_UNSUPPORTED && try_db; ++i) st = launch_pipe<S, TIO>(a, s, pp[i][0], pp[i][1], nsw, false);
       }
     }
     if (st != CRT_ERR_UNSUPPORTED) {

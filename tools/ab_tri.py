@@ -12,10 +12,11 @@ d = synth.make_columns(ncol, nb, nz, uniform_dlai=not ragged)
 cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
 plan = batched.Plan(scheme, cols, bands)
 lib = _lib.load()
-# (M, T, pipe?, store waves)
-variants = {"tile M12 T4": (12, 4, 0, 0), "tile M8 T8": (8, 8, 0, 0), "tile M12 T12": (12, 12, 0, 0), "tile M16 T8": (16, 8, 0, 0),
-            "pipe M12 T4 s3": (12, 4, 1, 3), "pipe M12 T4 s2": (12, 4, 1, 2), "pipe M12 T4 s4": (12, 4, 1, 4), "pipe M8 T4 s3": (8, 4, 1, 3),
-            "pipe M16 T4 s3": (16, 4, 1, 3), "pipe M16 T8 s3": (16, 8, 1, 3), "per-wave": None}
+# (M, T, tune key 10 [1 = k_tri_tile, 2 = double-buffer pipeline, 3 = register-staged pipeline], store waves)
+variants = {"tile M12 T12": (12, 12, 1, 0), "tile M16 T8": (16, 8, 1, 0),
+            "pipe-db M12 T4 s4": (12, 4, 2, 4), "pipe-db M8 T4 s3": (8, 4, 2, 3), "pipe-db M16 T4 s4": (16, 4, 2, 4),
+            "pipe-rs M12 T4 s3": (12, 4, 3, 3), "pipe-rs M12 T4 s4": (12, 4, 3, 4), "pipe-rs M16 T4 s3": (16, 4, 3, 3), "pipe-rs M8 T4 s3": (8, 4, 3, 3),
+            "auto": (0, 0, 0, 0), "per-wave": None}
 res = {k: [] for k in variants}
 plan(); torch.cuda.synchronize()  # K0 once: the timed launches below skip the precompute and reuse this workspace
 buf = torch.empty(2 * 10**9 // 8, dtype=torch.float64, device="cuda")
@@ -36,7 +37,7 @@ for rnd in range(5):
         if mt is None:
             flags |= _lib.FLAG_DIRECT_STORES
         else:
-            lib.crt_hip_tune(8, mt[0]); lib.crt_hip_tune(9, mt[1]); lib.crt_hip_tune(10, 0 if mt[2] else 1); lib.crt_hip_tune(11, mt[3])
+            lib.crt_hip_tune(8, mt[0]); lib.crt_hip_tune(9, mt[1]); lib.crt_hip_tune(10, mt[2]); lib.crt_hip_tune(11, mt[3])
         plan(flags=flags); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
@@ -46,4 +47,4 @@ for rnd in range(5):
         res[name].append(e0.elapsed_time(e1) / 5)
 for name, v in res.items():
     v = sorted(v)
-    print(f"{scheme} nz={nz} ragged={ragged} {name:16s} median {v[len(v)//2]:.4f} ms  min {v[0]:.4f} ms")
+    print(f"{scheme} nz={nz} ragged={ragged} {name:18s} median {v[len(v)//2]:.4f} ms  min {v[0]:.4f} ms")
