@@ -20,6 +20,8 @@
 //           stores at consecutive addresses, so every wave store covers 8 whole 128-B lines.
 //           T = 16/gcd(nb,16) (times a small factor) makes every run start on a line boundary.
 //  k_direct (small nb, or tile does not fit in LDS): the original lane-stores-its-band kernel.
+#include <algorithm>
+
 #include "crt_internal.hpp"
 
 namespace crt {
@@ -48,6 +50,7 @@ __device__ inline BandIn load_band(const SolveArgs& a, int c, int b, bool need_s
 struct Sch2s {
   static constexpr int NARR = 4;
   static constexpr bool SOIL = true;
+  static constexpr bool HEAVY_INIT = false;
   double h;                       // diffuse extinction              :84
   double Au, Bu, Cu, Ad, Bd, Cd;  // up/dn = A e^{-KL} + B e^{-hL} + C e^{+hL}   :125-135
   double I0, invmu;
@@ -133,6 +136,7 @@ struct Sch2s {
 struct SchBl {
   static constexpr int NARR = 4;
   static constexpr bool SOIL = false;
+  static constexpr bool HEAVY_INIT = false;
   double Kg, I_dr0, I_df0, invmu, tg, qg;
   bool unif;
 
@@ -165,6 +169,7 @@ template <bool BF>
 struct SchG77 {
   static constexpr int NARR = 7;
   static constexpr bool SOIL = true;
+  static constexpr bool HEAVY_INIT = false;
   double kb, invmu, LT, kp, kd, omr, cdf, csr, ct, gnd, I_dr0, I_df0, r, t;
   double ed, ex, er;      // e^{-kd L}, second scattered-light exponential (see level()), e^{-kd (LT - L)}
   double qd, qx, qr;      // their per-level factors for uniform dlai
@@ -292,6 +297,7 @@ __device__ inline void solve4(double (&A)[4][5]) {
 struct Sch4s {
   static constexpr int NARR = 4;
   static constexpr bool SOIL = true;
+  static constexpr bool HEAVY_INIT = true;  // eigen-decomposition + 4x4 solve per band before the first level: wants more workgroups per CU
   double lam1, lam2;  // sqrt(|l1|), sqrt(|l2|)
   bool osc;           // l2 < 0
   double d[5], u[5];  // I_df_d / I_df_u = sum_k coef[k] * phi_k(x), phi = {E1, F1, phi3, phi4, e^{-kappa x}}
@@ -607,7 +613,7 @@ struct PipeTileCfg {
   int rec_dbl;  // doubles reserved for the staged column record
 };
 
-template <class S, typename TIO, int MAXT>
+template <class S, typename TIO, int MAXT, bool FUSED>
 __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
   constexpr int VW = 16 / (int)sizeof(TIO);
   typedef TIO vt __attribute__((ext_vector_type(VW)));
@@ -642,6 +648,34 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
         }
       }
       lds_barrier();  // tile complete: hand it to the store waves
+      buf ^= 1;
+    }
+  } else if constexpr (!FUSED) {
+    // ---- store role, any nb / alignment: per array one flat run of Tc * nb elements (head up to the next 16-B boundary of
+    // the destination, 16-B vectors, tail), as k_tile's generic flush ----
+    const int sid = tid - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
+    int buf = 0;
+    for (int j0 = 0; j0 < nz; j0 += T) {
+      const int Tc = min(T, nz - j0);
+      lds_barrier();  // tile `buf` is complete
+      const int n = Tc * nb;
+      for (int k = 0; k < S::NARR; ++k) {
+        TIO* g = outp<TIO>(a.o[k]) + ((long long)c * nz + j0) * nb;
+        const TIO* src = tile + buf * bufrun + k * colrun;
+        int mis = (int)(((16 - (reinterpret_cast<uintptr_t>(g) & 15)) & 15) / sizeof(TIO));
+        if (mis > n) mis = n;
+        const int nvec = (n - mis) / VW;
+        const int tail = (n - mis) - nvec * VW;
+        vt* gv = reinterpret_cast<vt*>(g + mis);
+        for (int i = sid; i < nvec; i += nst) {
+          vt v;
+#pragma unroll
+          for (int w = 0; w < VW; ++w) v[w] = src[mis + VW * i + w];
+          gv[i] = v;
+        }
+        if (sid < mis) g[sid] = src[sid];
+        if (sid < tail) g[mis + nvec * VW + sid] = src[mis + nvec * VW + sid];
+      }
       buf ^= 1;
     }
   } else {
@@ -718,21 +752,35 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
   for (int i = 0; i < S::NARR && fused; ++i)
     if (reinterpret_cast<uintptr_t>(a.o[i]) & 15) fused = false;
   const int grid = (a.ncol + CB - 1) / CB;
-  if (fused && !(g_tune[2] & 4)) {  // wave-specialised pipeline (tune [2] bit2 disables, [3] = store waves, [4] = its T)
-    int nsw = g_tune[3] > 0 ? g_tune[3] : 3;
-    if (nthr + 64 * nsw > 1024) nsw = (1024 - nthr) / 64;
-    // two buffers of the longest line-aligned run that keeps two workgroups per CU
-    int Tp = Ta;
-    while (2 * per_level * (Tp + Ta) <= target && Tp + Ta <= a.nz) Tp += Ta;
+  // wave-specialised pipeline, always one column per workgroup (tune [2] bit2 disables it, bit3 disables its generic-flush
+  // form [odd nb, several columns per k_tile workgroup]; [3] = store waves, [4] = its T)
+  bool pfused = nb % VW == 0 && !(g_tune[2] & 2);  // the pipeline always has one column per workgroup
+  for (int i = 0; i < S::NARR && pfused; ++i)
+    if (reinterpret_cast<uintptr_t>(a.o[i]) & 15) pfused = false;
+  if (!(g_tune[2] & 4) && (pfused || !(g_tune[2] & 8))) {
+    const bool fused = pfused;  // (shadows k_tile's flag inside this block)
+    const int pcomp = ((nb + 63) / 64) * 64;
+    const size_t plevel = (size_t)S::NARR * nb * sizeof(TIO);
+    int nsw = g_tune[3] > 0 ? g_tune[3] : (pcomp <= 128 ? 2 : 3);
+    if (pcomp + 64 * nsw > 1024) nsw = (1024 - pcomp) / 64;
+    // Two tile buffers of up to 8 levels, line-aligned runs when they fit, at least two workgroups per CU -- and about four
+    // for a scheme with a heavy per-band set-up when the spectrum is narrow enough to allow it.  Measured (tools/ab_shapes.py,
+    // profiles/r01/ab_shapes.txt), k_tile -> k_pipe: 2s nb=107 1.325 -> 1.20 ms (T=8), nb=64 1.148 -> 0.97 (T=8), nb=128 1.173 -> 1.154,
+    // nb=200 no change; 4s nb=107 1.363 -> 1.24..1.29 (T=2..6; T=8 1.46), nb=64 1.231 -> 0.946; g77 nb=107 2.477 -> 2.24 (T=6).
+    // Longer tiles lose: T=11 at nb=128 leaves one workgroup per CU, 1.5 ms.
+    size_t budget = target;
+    if (S::HEAVY_INIT && 2 * plevel * 4 <= 40 * 1024) budget = 40 * 1024;
+    const int Tmax = (int)std::min<size_t>(8, budget / (2 * plevel));
+    int Tp = Ta <= Tmax ? (Tmax / Ta) * Ta : Tmax;
     if (g_tune[4] > 0) Tp = g_tune[4];
     if (Tp > a.nz) Tp = a.nz;
     PipeTileCfg pc;
-    pc.ncomp = nthr;
+    pc.ncomp = pcomp;
     pc.T = Tp;
     pc.rec_dbl = (a.reclen + 1) & ~1;
-    const size_t psh = pc.rec_dbl * sizeof(double) + 2 * per_level * Tp;
-    if (nsw >= 1 && psh <= 160 * 1024 && (2 * per_level * Ta <= target || g_tune[4] > 0)) {
-      const int pthr = nthr + 64 * nsw;
+    const size_t psh = pc.rec_dbl * sizeof(double) + 2 * plevel * Tp;
+    if (nsw >= 1 && Tp >= 2 && psh <= 160 * 1024 && (fused ? (2 * plevel * Ta <= target || g_tune[4] > 0) : true)) {
+      const int pthr = pcomp + 64 * nsw;
       auto gop = [&](auto kern) {
         if (psh > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh) != hipSuccess)
@@ -740,7 +788,9 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
         hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(pthr), psh, s, a, pc);
         return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
       };
-      const int st = pthr <= 512 ? gop(k_pipe<S, TIO, 512>) : gop(k_pipe<S, TIO, 1024>);
+      int st;
+      if (fused) st = pthr <= 512 ? gop(k_pipe<S, TIO, 512, true>) : gop(k_pipe<S, TIO, 1024, true>);
+      else st = pthr <= 512 ? gop(k_pipe<S, TIO, 512, false>) : gop(k_pipe<S, TIO, 1024, false>);
       done = st == CRT_OK;
       return st;
     }

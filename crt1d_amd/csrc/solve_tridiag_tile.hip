@@ -40,11 +40,10 @@ struct TriCfg {
 // flush one output array: rows [j0, j0 + nrows) of column c, one contiguous run
 template <class S, typename TIO, int ARR>
 __device__ inline void flush_array(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride,
-                                   int c, int j0, int nrows, double invmu, float inv_nb) {
+                                   int c, int j0, int nrows, double invmu, float inv_nb, int tid, int nthr) {
   if (nrows <= 0) return;
   typedef TIO vt __attribute__((ext_vector_type(2)));
   const int nb = a.nb, nz = a.nz;
-  const int tid = threadIdx.x, nthr = blockDim.x;
   const int n = nrows * nb;
   TIO* g = outp<TIO>(a.o[ARR]) + ((long long)c * S::out_rows(ARR, nz) + j0) * nb;
   const int mis = (int)((reinterpret_cast<uintptr_t>(g) / sizeof(TIO)) & 1);  // run starts on an odd element?
@@ -73,12 +72,13 @@ __device__ inline void flush_array(const SolveArgs& a, const double* rec, const 
   }
 }
 
+// tid / nthr: the threads that take part in the flush (all of the workgroup in k_tri_tile, the store waves in k_tri_pipe)
 template <class S, typename TIO, int ARR>
 __device__ inline void flush_arrays(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride, int c,
-                                    int j0, int T, double invmu, float inv_nb) {
+                                    int j0, int T, double invmu, float inv_nb, int tid, int nthr) {
   const int nr = min(j0 + T, S::out_rows(ARR, a.nz)) - j0;
-  flush_array<S, TIO, ARR>(a, rec, bandc, tile, tstride, c, j0, nr, invmu, inv_nb);
-  if constexpr (ARR + 1 < S::NOUT) flush_arrays<S, TIO, ARR + 1>(a, rec, bandc, tile, tstride, c, j0, T, invmu, inv_nb);
+  flush_array<S, TIO, ARR>(a, rec, bandc, tile, tstride, c, j0, nr, invmu, inv_nb, tid, nthr);
+  if constexpr (ARR + 1 < S::NOUT) flush_arrays<S, TIO, ARR + 1>(a, rec, bandc, tile, tstride, c, j0, T, invmu, inv_nb, tid, nthr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -200,7 +200,7 @@ __device__ __forceinline__ void tri_tile_body(const SolveArgs& a, const TriCfg& 
           if constexpr (FUSED)
             flush_fused<S, TIO, T>(a, rec, bandc, tile, c, k, fm, invmu);
           else
-            flush_arrays<S, TIO, 0>(a, rec, bandc, tile, tstride, c, k, T, invmu, inv_nb);
+            flush_arrays<S, TIO, 0>(a, rec, bandc, tile, tstride, c, k, T, invmu, inv_nb, tid, nthr);
           lds_barrier();
         }
       }
@@ -536,6 +536,33 @@ __device__ __forceinline__ void tri_pipe_store_rs(const SolveArgs& a, const Pipe
   }
 }
 
+// any nb / alignment: the generic flat flush of k_tri_tile, run by the store waves on the double-buffered tile
+template <class S, typename TIO, int M, int T>
+__device__ __forceinline__ void tri_pipe_store_generic(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
+  const int nb = a.nb, nz = a.nz;
+  const int c = blockIdx.x;
+  const int sid = threadIdx.x - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
+  const double* rec = lds;
+  const double* bandc = lds + cfg.off_bc;
+  const double* tile = lds + cfg.off_tile;
+  const int tstride = T * nb, bstride = S::NST * tstride;
+  const double invmu = rec[S_INVMU];
+  const float inv_nb = 1.0f / (float)nb;
+  const int K = S::rows(nz);
+  int buf = 0;
+  for (int seg = (K - 1) / M; seg >= 0; --seg) {
+    const int k0 = seg * M;
+    const int kend = min(k0 + M - 1, K - 1);
+    for (int i = M - T; i >= 0; i -= T) {
+      const int k = k0 + i;
+      if (k > kend) continue;
+      lds_barrier();  // tile `buf` is complete
+      flush_arrays<S, TIO, 0>(a, rec, bandc, tile + buf * bstride, tstride, c, k, min(T, kend - k + 1), invmu, inv_nb, sid, nst);
+      buf ^= 1;
+    }
+  }
+}
+
 template <class S, typename TIO, int M, int T>
 __device__ __forceinline__ void tri_pipe_store(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
   const int nb2 = a.nb >> 1, nz = a.nz;
@@ -604,6 +631,8 @@ __global__ __launch_bounds__(MAXT) void k_tri_pipe(SolveArgs a, PipeCfg cfg) {
   if ((int)threadIdx.x >= cfg.ncomp) {
     if constexpr (RS > 0)
       tri_pipe_store_rs<S, TIO, M, T, RS>(a, cfg, lds);
+    else if constexpr (RS < 0)
+      tri_pipe_store_generic<S, TIO, M, T>(a, cfg, lds);
     else
       tri_pipe_store<S, TIO, M, T>(a, cfg, lds);
     return;
@@ -620,6 +649,28 @@ __global__ __launch_bounds__(MAXT) void k_tri_pipe(SolveArgs a, PipeCfg cfg) {
 
 // returns CRT_ERR_UNSUPPORTED when the shape does not fit (caller falls back to k_tri_tile)
 constexpr int PIPE_RS = 4;  // band pairs a store thread holds in the register-staged variant
+
+template <class S, typename TIO, int M, int T>
+int launch_pipe_generic(const SolveArgs& a, hipStream_t s, int nstore_waves) {
+  const int ncomp = ((a.nb + 63) / 64) * 64;
+  const int nthr = ncomp + 64 * nstore_waves;
+  if (nthr > 512) return CRT_ERR_UNSUPPORTED;  // instantiated for narrow spectra only (the odd-nb case that matters: nb = 107)
+  const int K = S::rows(a.nz);
+  PipeCfg cfg;
+  cfg.ncomp = ncomp;
+  cfg.nck = (K - 1) / M + 1;
+  cfg.off_bc = (a.reclen + 1) & ~1;
+  cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
+  cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
+  const size_t sh = ((size_t)cfg.off_tile + (size_t)2 * S::NST * T * a.nb) * sizeof(double);
+  if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
+  auto kern = k_tri_pipe<S, TIO, M, T, 512, -1>;
+  if (sh > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+    return CRT_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, cfg);
+  return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+}
 
 template <class S, typename TIO, int M, int T>
 int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves, bool regstage) {
@@ -690,6 +741,19 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 64
   bool fused = (a.nb % 2 == 0);
   for (int i = 0; i < S::NOUT && fused; ++i)
     if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) fused = false;
+  // odd nb / unaligned outputs: pipeline with the generic flush.  The per-element flush is too much work for a few store
+  // waves once the spectrum is wide (tools/ab_tri_odd.py, k_tri_tile -> pipeline with 2 store waves: nb=107 n79 1.81 -> 1.90 ms,
+  // zq 2.35 -> 2.29, zq nz=100 3.00 -> 2.22; nb=255 n79 1.60 -> 2.39, zq 2.25 -> 2.86), so only narrow spectra take it
+  // (tune key 10 = 4 forces it for any nb).
+  if (!fused && g_tri_tune[2] != 1 && g_tri_tune[0] == 0 && (nthr <= 128 || g_tri_tune[2] == 4)) {
+    const int nsw = g_tri_tune[3] > 0 ? g_tri_tune[3] : 2;
+    int st = launch_pipe_generic<S, TIO, 12, 4>(a, s, nsw);
+    if (st == CRT_ERR_UNSUPPORTED) st = launch_pipe_generic<S, TIO, 16, 4>(a, s, nsw);
+    if (st != CRT_ERR_UNSUPPORTED) {
+      done = st == CRT_OK;
+      return st;
+    }
+  }
   if (fused && g_tri_tune[2] != 1) {  // wave-specialised pipeline first (tune key 10 = 1 disables, key 11 = store waves)
     // Measured on MI355X at 1e4 x 300 (tools/ab_tri.py, profiles/r01/ab_tri_pipe_*.txt; fill probe 6.3-6.8 TB/s):
     //                best k_tri_tile -> double-buffer pipeline (1 WG/CU) -> register-staged pipeline (2 WG/CU)

@@ -1,0 +1,37 @@
+"""A/B k_tile vs k_pipe for band counts away from the tuned 300 (odd nb, several columns per k_tile workgroup)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from crt1d_amd import _lib, batched, synth
+
+lib = _lib.load()
+st = torch.cuda.current_stream()
+for scheme, ncol, nb, nz in [("2s", 30000, 107, 60), ("4s", 30000, 107, 60), ("g77", 30000, 107, 60), ("2s", 40000, 64, 60), ("4s", 40000, 64, 60),
+                             ("2s", 24000, 128, 60), ("4s", 24000, 128, 60), ("2s", 16000, 200, 60)]:
+    d = synth.make_columns(ncol, nb, nz)
+    cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
+    plan = batched.Plan(scheme, cols, bands)
+    plan(); torch.cuda.synchronize()
+    variants = {"tile": {2: 4, 3: 0, 4: 0}}
+    for T in (2, 4, 6, 8, 11):
+        for sw in (1, 2, 3):
+            variants[f"T{T}s{sw}"] = {2: 0, 3: sw, 4: T}
+    res = {k: [] for k in variants}
+    for rnd in range(3):
+        for name, tune in variants.items():
+            for k, v in tune.items():
+                lib.crt_hip_tune(k, v)
+            flags = _lib.FLAG_SKIP_PRECOMPUTE
+            plan(flags=flags); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(5):
+                plan(st, flags=flags)
+            e1.record(st); torch.cuda.synchronize()
+            res[name].append(e0.elapsed_time(e1) / 5)
+    gb = sum(v.numel() * 8 for v in plan.out.values()) / 1e9
+    print(f"{scheme} {ncol}x{nb}x{nz} ({gb:.2f} GB): " + "  ".join(f"{k} {sorted(v)[len(v)//2]:.3f}" for k, v in res.items()), flush=True)
+    for k in (2, 3, 4):
+        lib.crt_hip_tune(k, 0)
+    del plan, cols, bands
+    torch.cuda.empty_cache()
