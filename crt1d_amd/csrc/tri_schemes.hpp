@@ -185,7 +185,6 @@ struct TriZq {
   static constexpr int NST = 4;   // staged: I_df_d, I_df_u, I_df_d_ss, I_df_u_ss
   static constexpr int NOUT = 7;  // I_dr, I_df_d, I_df_u, F, I_df_d_ss, I_df_u_ss, F_ss
   double I_dr0, I_df0, rho, fwd, q, q0, cu, cd, invmu;
-  double i_int, i_lo1;  // 1/(1 - q q), 1/(1 - q0 q): the only values 1/dlo, 1/dhi take besides 1
   double xd, xu;  // SWd0[li], SWu0[li] of the level above
 
   __host__ __device__ static inline int rows(int nz) { return nz + 1; }
@@ -209,8 +208,6 @@ struct TriZq {
     q0 = 1.0 * (1 - (1 - rho)) * (1 - 0.0);  // ground "layer": r=1, t=0, a=1-rho (:106-108)
     cu = r_psi * (1 - t_psi) * (1 - aL);        // :139
     cd = (1 - t_psi) * (1 - aL) * (1 - r_psi);  // :142
-    i_int = fast_rcp(1 - q * q);
-    i_lo1 = fast_rcp(1 - q0 * q);
   }
   __device__ inline void first(const double* rec, int nz, double& e, double& f) const {
     e = 0.0;  // row 0: x0 = rho S_0 (:115,136)
@@ -245,10 +242,13 @@ struct TriZq {
     const double qlo = (li == 1) ? q0 : q;
     const double qhi = (li == m) ? 0.0 : q;
     const double dhi = 1 - q * qhi;
+    const double dlo = 1 - qlo * q;
     // SWd0[li-1] from the original row 2li:  dhi x_{2li-1} - qhi fwd x_{2li} - fwd x_{2li+1} = C
-    const double xdl = (dhi * cd * S + qhi * fwd * xu + fwd * xd) * ((li == m) ? 1.0 : i_int);  // 1/dhi
+    // (1/dhi and 1/dlo take three values per band; keeping them in registers costs the integrated kernel a wave of
+    // occupancy -- 96 -> 98 VGPRs, 1.19 -> 1.45 ms -- and the profile kernels are store-bound, so they are recomputed)
+    const double xdl = (dhi * cd * S + qhi * fwd * xu + fwd * xd) * fast_rcp(dhi);
     const double xul = f - e * xdl;  // SWu0[li-1]
-    const double iden = (li == 1) ? i_lo1 : i_int;  // 1/dlo; multiple-scattering correction, eqs. 24/25 (:180-187)
+    const double iden = fast_rcp(dlo);   // multiple-scattering correction, eqs. 24/25 (:180-187)
     o[0] = (xd + q * xul) * iden;
     o[1] = (xul + qlo * xd) * iden;
     o[2] = xd;   // I_df_d_ss :197
