@@ -308,3 +308,49 @@ def test_model_to_dataset():
             m.to_xr()
     else:
         assert set(m.to_xr().data_vars) == expected
+
+
+# (tune key, value) settings that select each kernel family through crt_hip_tune (keys: solve_closed.hip g_tune, solve_tridiag_tile.hip
+# g_tri_tune = keys 8..11)
+_CLOSED_PATHS = {"k_pipe (default)": {}, "k_tile": {2: 4}, "k_tile generic flush": {2: 4 | 2}, "k_pipe generic flush": {2: 2},
+                 "k_pipe 1 store wave, T=2": {3: 1, 4: 2}, "k_pipe 4 store waves, T=8": {3: 4, 4: 8}}
+_TRI_PATHS = {"default": {}, "k_tri_tile": {10: 1}, "k_tri_tile M8 T8": {10: 1, 8: 8, 9: 8}, "double-buffer pipeline": {10: 2},
+              "register-staged pipeline": {10: 3}, "generic-flush pipeline": {10: 4}, "pipeline M16 T4, 2 store waves": {8: 16, 9: 4, 11: 2}}
+
+
+@pytest.mark.parametrize("scheme", ["2s", "4s", "bl", "g77", "bf", "n79", "zq"])
+@pytest.mark.parametrize("shape", [(23, 300, 60), (9, 107, 61), (6, 64, 13), (5, 128, 60), (3, 600, 33), (4, 255, 100), (7, 300, 7)])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_every_kernel_family_gives_the_same_bits(scheme, shape, dtype):
+    """The wave-specialised pipelines (double-buffered, register-staged, generic flush), the all-waves tile kernels and the
+    per-wave / direct kernels share the per-lane arithmetic; whichever the heuristics pick, the outputs are BITWISE equal."""
+    import torch
+
+    from crt1d_amd import _lib, batched, synth
+
+    lib = _lib.load()
+    ncol, nb, nz = shape
+    d = synth.make_columns(ncol, nb, nz, seed=13, uniform_dlai=(ncol % 2 == 1))
+    if dtype == "f32":
+        d = {k: (v.astype(np.float32) if k in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r") else v) for k, v in d.items()}
+    cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
+    ref = batched.Plan(scheme, cols, bands)
+    ref(flags=_lib.FLAG_DIRECT_STORES)
+    paths = _TRI_PATHS if scheme in ("n79", "zq") else _CLOSED_PATHS
+    keys = sorted({k for t in paths.values() for k in t})
+    try:
+        for name, tune in paths.items():
+            for k in keys:
+                lib.crt_hip_tune(k, tune.get(k, 0))
+            p = batched.Plan(scheme, cols, bands)
+            for v in p.out.values():
+                v.fill_(float("nan"))
+            p()
+            torch.cuda.synchronize()
+            for k in p.out:
+                assert bool(torch.isfinite(p.out[k]).all()), (name, k)
+                assert torch.equal(p.out[k], ref.out[k]), (name, k)
+    finally:
+        for k in keys:
+            lib.crt_hip_tune(k, 0)
+        lib.crt_hip_tune(0, 78 * 1024)
