@@ -34,7 +34,7 @@ def _default_fns():
 
 
 def solve_sharded(scheme, cols, bands, band_w, *, partition="column", group=None, solve_fn=None, epilogue_fn=None,
-                  keep_profiles=True, integrated_fn=None, **opts):
+                  keep_profiles=True, integrated_fn=None, column_tiles=1, **opts):
     """Solve this rank's shard and return spectrally integrated results.
 
     ``cols`` / ``bands``: the FULL problem (objects with ``.ncol``, ``.nb``, ``.slice(lo, hi)``, ``.band_slice(lo, hi)``;
@@ -46,6 +46,10 @@ def solve_sharded(scheme, cols, bands, band_w, *, partition="column", group=None
     With ``partition="band"`` every rank ends up with the complete integrated result for all columns.
     ``keep_profiles=False`` uses the fused kernel (``crt_hip_integrated_f64``): no profile is ever written to HBM and
     ``profiles`` is ``None``.
+    ``column_tiles > 1`` (band partition): the columns are processed in that many tiles and the all-reduce of tile i is
+    issued asynchronously while tile i+1 is being solved (at the HBM roofline the reduce of the
+    ~80 MB messages of config 4 is comparable to the solve, so it should hide behind it); ``profiles`` is then a list with one
+    entry per tile.
     """
     if solve_fn is None or epilogue_fn is None:
         s, e = _default_fns()
@@ -70,18 +74,36 @@ def solve_sharded(scheme, cols, bands, band_w, *, partition="column", group=None
     elif partition == "band":
         lo, hi = block_range(bands.nb, rank, world)
         b = bands.band_slice(lo, hi)
-        sol = solve_fn(scheme, cols, b, **opts)
         bw = band_w[:, lo:hi].contiguous()
-        res = epilogue_fn(cols, b, sol, bw) if keep_profiles else dict(fused(scheme, cols, b, bw, **opts))
-        if world > 1:
-            keys = ("aI", "aI_sl", "aI_sh", "totals")
-            flat = torch.cat([res[k].reshape(-1) for k in keys])  # one packed message
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        keys = ("aI", "aI_sl", "aI_sh", "totals")
+        ntile = max(1, min(int(column_tiles), cols.ncol))
+        tiles = []  # (partial results, packed buffer, pending all-reduce)
+        sols = []
+        for t in range(ntile):
+            clo, chi = block_range(cols.ncol, t, ntile)
+            ct, bt = (cols, b) if ntile == 1 else (cols.slice(clo, chi), b.slice(clo, chi))
+            sol_t = solve_fn(scheme, ct, bt, **opts)
+            res_t = epilogue_fn(ct, bt, sol_t, bw) if keep_profiles else dict(fused(scheme, ct, bt, bw, **opts))
+            flat, work = None, None
+            if world > 1:
+                flat = torch.cat([res_t[k].reshape(-1) for k in keys])  # one packed message per tile
+                # asynchronous: the next tile's kernels are enqueued while this message is on the wire
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=ntile > 1)
+            tiles.append((res_t, flat, work))
+            sols.append(sol_t)
+        parts = {k: [] for k in keys}
+        for res_t, flat, work in tiles:
+            if work is not None:
+                work.wait()
             off = 0
             for k in keys:
-                n = res[k].numel()
-                res[k] = flat[off:off + n].view_as(res[k])
-                off += n
+                if flat is not None:
+                    n = res_t[k].numel()
+                    res_t[k] = flat[off:off + n].view_as(res_t[k])
+                    off += n
+                parts[k].append(res_t[k])
+        res = {k: (v[0] if ntile == 1 else torch.cat(v, dim=0)) for k, v in parts.items()}
+        sol = sols[0] if ntile == 1 else sols
         col_range = (0, cols.ncol)
     else:
         raise ValueError("partition must be 'column' or 'band'")

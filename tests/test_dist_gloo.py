@@ -78,6 +78,12 @@ def _worker(rank, world, port, scheme, q):
         cols, bands = HostCols(d), HostBands(d)
         rb = solve_sharded(scheme, cols, bands, bw, partition="band", solve_fn=solve_fn, epilogue_fn=epi)
         rc = solve_sharded(scheme, cols, bands, bw, partition="column", solve_fn=solve_fn, epilogue_fn=epi)
+        # column tiles with overlapped (asynchronous) all-reduces must give the same integrated results as one message
+        rt = solve_sharded(scheme, cols, bands, bw, partition="band", solve_fn=solve_fn, epilogue_fn=epi, column_tiles=3)
+        assert isinstance(rt["profiles"], list) and len(rt["profiles"]) == 3
+        for k in ("aI", "aI_sl", "aI_sh", "totals", "reflectance"):
+            assert rt[k].shape == rb[k].shape
+            np.testing.assert_allclose(rt[k].numpy(), rb[k].numpy(), rtol=1e-13, atol=1e-300)
         full_c = {k: gather_columns(rc[k], NCOL) for k in ("aI", "aI_sl", "aI_sh", "totals", "reflectance")}
         q.put((rank, {k: rb[k].numpy() for k in full_c}, {k: v.numpy() for k, v in full_c.items()}, rc["columns"],
                tuple(rb["profiles"]["I_dr"].shape)))

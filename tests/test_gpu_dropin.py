@@ -227,6 +227,10 @@ def test_dist_paths_on_the_hip_kernels(oracle, scheme):
     assert rc["columns"] == (0, 23) and rb["columns"] == (0, 23)
     for k in ("aI", "aI_sl", "aI_sh", "totals", "reflectance"):
         assert torch.equal(rc[k], rb[k]), k
+    rt = solve_sharded(scheme, cols, bands, w, partition="band", column_tiles=4)  # column tiles (23 -> 6,6,6,5): same kernels
+    assert len(rt["profiles"]) == 4 and rt["profiles"][3]["I_dr"].shape == (5, 60, 300)
+    for k in ("aI", "aI_sl", "aI_sh", "totals", "reflectance"):
+        assert torch.equal(rt[k], rb[k]), k
     rf = solve_sharded(scheme, cols, bands, w, partition="band", keep_profiles=False)  # fused kernel, no profiles
     assert rf["profiles"] is None
     for k in ("aI", "aI_sl", "aI_sh", "totals", "reflectance"):
