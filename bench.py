@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scheme", default="2s", choices=sorted(N_IO))
+    ap.add_argument("--placement", default="auto", choices=["auto", "none"], help="output-buffer placement search at plan creation")
     ap.add_argument("--ncol", type=int, default=10000, help="columns PER GPU")
     ap.add_argument("--nb", type=int, default=300)
     ap.add_argument("--nz", type=int, default=60)
@@ -220,7 +221,9 @@ def main():
 
         plan = batched.IntegratedPlan(scheme, cols, bands, torch.as_tensor(spectra.band_weights(d["wle"])).to(dev))
     else:
-        plan = batched.Plan(scheme, cols, bands)
+        # output buffers are allocated once, before the timed region; placement="auto" lets the plan pick where they live
+        # (the same kernel runs ~15 % faster or slower depending on where the driver put them)
+        plan = batched.Plan(scheme, cols, bands, placement=a.placement)
     stream = torch.cuda.current_stream(dev)
 
     def barrier():
@@ -316,6 +319,7 @@ def main():
                         f"solve_{scheme} batched: {ncol} synthetic profiles x {nb} bands x {nz} levels per GPU, fp64",
             "scheme": scheme, "ncol_per_gpu": ncol, "nb": nb, "nz": nz, "partition": "column blocks, no collective",
             "step": "K0 column precompute + solve kernel via crt_hip_%s_f64" % scheme,
+            "output_placement": getattr(plan, "placement_report", None),
         },
         "roofline": {
             "bound": "hbm",

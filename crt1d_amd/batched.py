@@ -11,6 +11,7 @@ the reference's ``(nz, nb)`` solver outputs (e.g. ``_solve_2s.py:45-49``) stacke
 """
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -219,7 +220,8 @@ class Plan:
     """Pre-validated launch of one scheme on fixed buffers: ``plan()`` enqueues K0 + the solve kernel
     on the current stream with no allocation and no host synchronisation (bench / steady-state use)."""
 
-    def __init__(self, scheme, cols: Columns, bands: Bands, *, mu_s=0.501, tau_d_method="quad", out=None, workspace=None):
+    def __init__(self, scheme, cols: Columns, bands: Bands, *, mu_s=0.501, tau_d_method="quad", out=None, workspace=None,
+                 placement="none"):
         if scheme not in _lib.SCHEME_IDS:
             raise ValueError(f"unknown scheme {scheme!r}; valid: {', '.join(SCHEMES)}")
         if tau_d_method not in _lib.TAU_D_METHODS:
@@ -246,14 +248,78 @@ class Plan:
         self._c = cols.c_struct()
         self._b = bands.c_struct(ncol)
         self._o = _lib.CrtOptions(float(mu_s), _lib.TAU_D_METHODS[tau_d_method], 0)
-        ptrs = [self.out[k].data_ptr() for k in OUT_KEYS[scheme]]
-        ptrs += [None] * (7 - len(ptrs))
-        self._out = _lib.CrtOutputs(*ptrs)
         if bands.dtype == torch.float32 and scheme not in _lib.F32_SCHEMES:
             raise TypeError(f"scheme {scheme!r} has no f32 storage variant yet")
         self._entry = f"crt_hip_{scheme}_{'f32' if bands.dtype == torch.float32 else 'f64'}"
         self._fn = getattr(self.lib, self._entry)
         self._wsb = workspace.numel() * workspace.element_size()
+        self._point_at(self.out)
+        self.placement_report = None
+        if placement == "auto" and out is None and os.environ.get("CRT1D_PLACEMENT", "auto") != "none":
+            self._choose_placement()
+        elif placement not in ("auto", "none"):
+            raise ValueError("placement must be 'auto' or 'none'")
+
+    def _point_at(self, out):
+        self.out = out
+        ptrs = [out[k].data_ptr() for k in OUT_KEYS[self.scheme]]
+        ptrs += [None] * (7 - len(ptrs))
+        self._out = _lib.CrtOutputs(*ptrs)
+
+    def _time_ms(self, reps=3):
+        dev = self.cols.device
+        st = torch.cuda.current_stream(dev)
+        self(st, flags=_lib.FLAG_SKIP_PRECOMPUTE)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            self(st, flags=_lib.FLAG_SKIP_PRECOMPUTE)
+        e1.record(st)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def _choose_placement(self, nsets=3, nmix=6, seed=0x5EED):
+        """Pick WHERE the output arrays live.  The solve kernels are HBM-write-bound, and on MI355X the same kernel on the same
+        data runs in one of two modes depending on where the driver happened to place the output arrays in HBM: ~0.93 ms or
+        ~1.12 ms for 2s at 1e4 x 300 x 60, stable for the life of the allocation, nothing to do with their virtual addresses
+        (the slow mode shows twice the DRAM-credit stalls at the L2).  Since a Plan's buffers are
+        allocated once and reused, it is worth a fraction of a second: allocate a few candidate sets (each after a random-size
+        pad, which moves where the next allocation lands), time the solve on each, try a few mixes of arrays across sets, keep
+        the fastest and free the rest.  Skipped when the candidates would not fit comfortably in free memory."""
+        import random
+
+        dev = self.cols.device
+        total = sum(v.numel() * v.element_size() for v in self.out.values())
+        free, _ = torch.cuda.mem_get_info(dev)
+        if total < (256 << 20) or (nsets - 1) * total + (1 << 30) > free // 2:
+            return
+        with torch.cuda.device(dev):
+            rng = random.Random(seed)
+            self()  # K0 once: the timings below reuse the column records
+            sets, pads, times = [self.out], [], []
+            for _ in range(nsets - 1):
+                pads.append(torch.empty(rng.randrange(1, 150) << 21, dtype=torch.uint8, device=dev))
+                sets.append({k: torch.empty_like(v) for k, v in self.out.items()})
+            for s in sets:
+                self._point_at(s)
+                times.append(self._time_ms())
+            best, tbest, tworst = sets[times.index(min(times))], min(times), max(times)
+            tried = len(times)
+            keys = list(self.out)
+            for _ in range(nmix):
+                if tbest <= 0.92 * tworst:  # the two modes are ~15 % apart: the fast one has been found
+                    break
+                cand = {k: sets[rng.randrange(nsets)][k] for k in keys}
+                self._point_at(cand)
+                t = self._time_ms()
+                tried += 1
+                tworst = max(tworst, t)
+                if t < tbest:
+                    best, tbest = cand, t
+            self._point_at(best)
+            self.placement_report = {"candidates_timed": tried, "best_ms": tbest, "worst_ms": tworst}
+            del sets, pads
+            torch.cuda.empty_cache()
 
     def __call__(self, stream=None, *, flags=0):
         """Enqueue on ``stream`` (default: torch's current stream).  ``flags``: ``_lib.FLAG_SKIP_PRECOMPUTE`` reuses

@@ -113,6 +113,7 @@ __host__ __device__ inline void g4_interval(double mu_s, int iv, double& lo, dou
 }
 
 constexpr int K0_BLOCK = 128;
+constexpr int BL_UNIF_MAX_NZ = 512;
 
 __device__ inline double tau_d_quad(const double* kq, double L) {
   double s = 0.0;
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   __shared__ double sh_kb, sh_dlm, sh_dl, sh_tdu;
   __shared__ int sh_unif;
   __shared__ double xis[104];  // zq_pa: cumulative LAI of the computational interfaces
+  __shared__ double bl_part[K0_BLOCK / 64][BL_UNIF_MAX_NZ];  // bl, equal dLAI: per-wave partial tau_d sums of every level
 
   const int c = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -280,6 +282,23 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
     }
     __syncthreads();
   }
+  // bl on an equal-dLAI column: tau_d is needed at every level L_j = (nz-1-j) dl.  Instead of 96 exponentials per level
+  // (the kernel's whole cost: 5760 fp64 exps per column), thread q carries E_q^m = exp(-K_q dl)^m down the levels by one
+  // multiplication per level (drift <= nz ulp) and the 96 terms of a level are summed with DPP reductions.
+  const bool blu = a.scheme == CRT_SCHEME_BL && sh_unif != 0 && nz <= BL_UNIF_MAX_NZ;
+  if (blu) {
+    const double dl = sh_dl;
+    const bool on = tid < NQT;
+    const double E = on ? exp(-kq[on ? tid : 0] * dl) : 0.0;
+    const double w = on ? qc.w2sc[tid] : 0.0;
+    double P = 1.0;  // level nz-1: L = 0
+    for (int j = nz - 1; j >= 0; --j) {
+      const double t = wave_sum_lane63(w * P);
+      if (lane == 63) bl_part[wave][j] = t;
+      P *= E;
+    }
+    __syncthreads();
+  }
   double* v = rec + REC_HDR;
   for (int j = tid; j < nz; j += K0_BLOCK) {
     const double L = lai[j];
@@ -308,7 +327,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
       case CRT_SCHEME_BL:
         v[j] = L;
         v[nz + j] = ekl;
-        v[2 * nz + j] = tau_d_quad(kq, L);  // _solve_bl.py:35-37
+        v[2 * nz + j] = blu ? bl_part[0][j] + bl_part[1][j] : tau_d_quad(kq, L);  // _solve_bl.py:35-37
         break;
       case CRT_SCHEME_N79: {
         v[j] = ekl;  // tbcum  _solve_n79.py:46

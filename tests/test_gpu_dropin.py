@@ -358,3 +358,31 @@ def test_every_kernel_family_gives_the_same_bits(scheme, shape, dtype):
         for k in keys:
             lib.crt_hip_tune(k, 0)
         lib.crt_hip_tune(0, 78 * 1024)
+
+
+def test_plan_placement_auto():
+    """placement="auto" only changes WHERE the output arrays live (a few candidate allocations are timed, the fastest kept):
+    same results, a report of what was tried, and no effect on small problems or caller-provided buffers."""
+    import torch
+
+    from crt1d_amd import batched, synth
+
+    d = synth.make_columns(1600, 300, 60, seed=6)  # 4 x 230 MB of outputs: above the 256 MB threshold
+    cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
+    ref = batched.Plan("2s", cols, bands)
+    ref()
+    p = batched.Plan("2s", cols, bands, placement="auto")
+    assert p.placement_report is not None and p.placement_report["candidates_timed"] >= 3
+    assert p.placement_report["best_ms"] <= p.placement_report["worst_ms"]
+    for v in p.out.values():
+        v.fill_(float("nan"))
+    p()
+    torch.cuda.synchronize()
+    for k in ref.out:
+        assert torch.equal(p.out[k], ref.out[k]), k
+    small = batched.Plan("2s", batched.Columns.from_host(synth.make_columns(8, 64, 10)), batched.Bands.from_host(synth.make_columns(8, 64, 10)),
+                         placement="auto")
+    assert small.placement_report is None
+    assert batched.Plan("2s", cols, bands, out=ref.out, placement="auto").placement_report is None  # caller's buffers are kept
+    with pytest.raises(ValueError):
+        batched.Plan("2s", cols, bands, placement="best")
