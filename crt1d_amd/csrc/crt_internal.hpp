@@ -352,6 +352,15 @@ int init_quadrature(hipStream_t s);
 void tune_closed(int key, int value);
 void tune_tridiag(int key, int value);
 int launch_tridiag_tile(int scheme, const SolveArgs& a, hipStream_t s, bool& done);
+// per-(scheme, storage type) instantiation units: tri_inst.hip compiled four times
+int launch_tri_tile_n79_f64(const SolveArgs& a, hipStream_t s, bool& done);
+int launch_tri_tile_n79_f32(const SolveArgs& a, hipStream_t s, bool& done);
+int launch_tri_tile_zq_f64(const SolveArgs& a, hipStream_t s, bool& done);
+int launch_tri_tile_zq_f32(const SolveArgs& a, hipStream_t s, bool& done);
+int launch_tri_int_n79_f64(const SolveArgs& a, const IntArgs& ia, hipStream_t s);
+int launch_tri_int_n79_f32(const SolveArgs& a, const IntArgs& ia, hipStream_t s);
+int launch_tri_int_zq_f64(const SolveArgs& a, const IntArgs& ia, hipStream_t s);
+int launch_tri_int_zq_f32(const SolveArgs& a, const IntArgs& ia, hipStream_t s);
 int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s);
 int launch_zqpa_wave(const SolveArgs& g, hipStream_t s);  // per-wave fallback of the computational-grid solve
 __host__ __device__ inline int zqpa_M(int nz) { return nz < 100 ? nz : 100; }

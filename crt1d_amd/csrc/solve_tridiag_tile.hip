@@ -1,904 +1,27 @@
-// Tridiagonal schemes (n79, zq), column-tile kernel for gfx950.
-//
-// Why a second kernel: the per-wave kernels of solve_tridiag.hip keep 16 nz bytes of Thomas state per lane in
-// LDS (2 waves per CU at nz = 60) and let every lane store its own band (512-B runs that are only 8-B aligned when
-// nb*8 is not a multiple of 128 B).  Both hurt: 0.33-0.37 of HBM peak.  Here
-//
-//  * a workgroup owns ONE whole column (all nb bands), so -- as in k_tile of solve_closed.hip -- T consecutive
-//    levels of an output array are one contiguous run that is staged in LDS and flushed with 16-B-per-lane stores
-//    covering whole 128-B lines;
-//  * the Thomas state is CHECKPOINTED: the forward sweep keeps the even-row pair (e, f) only every M-th level
-//    (nz/M pairs per lane in LDS).  The back substitution walks the segments from the top; for each segment it
-//    re-runs the forward recurrence from the segment's checkpoint into M-1 register-resident pairs and then
-//    back-substitutes through them.  Every pair is produced by exactly the arithmetic of the plain sweep, so the
-//    result is bitwise what the per-wave kernel computes -- no unstable "shooting" recurrences -- at the price
-//    of running the (cheap) forward recurrence twice.  LDS per lane drops from 16 nz to 16 nz/M bytes;
-//  * only the 4 profiles that need the solve (dn, up and the two scheme extras) go through the LDS tile; I_dr and
-//    the F arrays are linear combinations with per-band / per-level constants and are formed while flushing.
-//
-// LDS at nb = 300, nz = 60, M = 12, T = 4: checkpoints 25.6 KB + tile 38.4 KB + record/band constants 5.4 KB
-// = 69 KB -> two workgroups (10 waves) per CU.
-#include <type_traits>
-
+// Dispatch of the tridiagonal column-tile / pipeline kernels.  The kernels themselves are templates in tri_tile_impl.hpp,
+// instantiated per (scheme, storage type) from tri_inst.hip and in tri_zqpa.hip (separate translation units: parallel compilation).
 #include "crt_internal.hpp"
-#include "tri_schemes.hpp"
 
 namespace crt {
-namespace {
 
-constexpr size_t MAX_WG_LDS = 160 * 1024;
-
-struct TriCfg {
-  int T;        // levels per flush tile (divides M)
-  int nck;      // checkpoints per lane
-  int off_bc;   // LDS offsets in doubles: band constants
-  int off_ck;   // checkpoints [nck][2][nthr]
-  int off_tile; // tile [NST][T][nb]
-};
-
-// ------------------------------------------------------------------------------------------
-// flush one output array: rows [j0, j0 + nrows) of column c, one contiguous run
-template <class S, typename TIO, int ARR>
-__device__ inline void flush_array(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride,
-                                   int c, int j0, int nrows, double invmu, float inv_nb, int tid, int nthr) {
-  if (nrows <= 0) return;
-  typedef TIO vt __attribute__((ext_vector_type(2)));
-  const int nb = a.nb, nz = a.nz;
-  const int n = nrows * nb;
-  TIO* g = outp<TIO>(a.o[ARR]) + ((long long)c * S::out_rows(ARR, nz) + j0) * nb;
-  const int mis = (int)((reinterpret_cast<uintptr_t>(g) / sizeof(TIO)) & 1);  // run starts on an odd element?
-  const int npair = (n - mis) >> 1;
-  auto elem = [&](int i) -> double {
-    if constexpr (S::derived(ARR)) {
-      int t = (int)(((float)i + 0.5f) * inv_nb);
-      int b = i - t * nb;
-      if (b < 0) { --t; b += nb; }
-      if (b >= nb) { ++t; b -= nb; }
-      return S::template value<ARR>(rec, nz, j0 + t, bandc[b], invmu, tile, tstride, i);
-    } else {
-      return tile[S::staged_slot(ARR) * tstride + i];
-    }
-  };
-  vt* g2 = reinterpret_cast<vt*>(g + mis);
-  for (int i = tid; i < npair; i += nthr) {
-    vt v;
-    v.x = (TIO)elem(mis + 2 * i);
-    v.y = (TIO)elem(mis + 2 * i + 1);
-    g2[i] = v;
-  }
-  if (tid == 0) {
-    if (mis) g[0] = (TIO)elem(0);
-    if ((n - mis) & 1) g[n - 1] = (TIO)elem(n - 1);
-  }
-}
-
-// tid / nthr: the threads that take part in the flush (all of the workgroup in k_tri_tile, the store waves in k_tri_pipe)
-template <class S, typename TIO, int ARR>
-__device__ inline void flush_arrays(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride, int c,
-                                    int j0, int T, double invmu, float inv_nb, int tid, int nthr) {
-  const int nr = min(j0 + T, S::out_rows(ARR, a.nz)) - j0;
-  flush_array<S, TIO, ARR>(a, rec, bandc, tile, tstride, c, j0, nr, invmu, inv_nb, tid, nthr);
-  if constexpr (ARR + 1 < S::NOUT) flush_arrays<S, TIO, ARR + 1>(a, rec, bandc, tile, tstride, c, j0, T, invmu, inv_nb, tid, nthr);
-}
-
-// ------------------------------------------------------------------------------------------
-// Fused flush for even nb (a band pair never straddles a row and every row is 16-B aligned): thread -> (row offset,
-// band pair) is fixed for the whole kernel, so there is no index arithmetic per element; the 4 staged pairs are read
-// once and all NOUT arrays are stored in the same pass.  Rows of a tile are adjacent in memory, so consecutive threads
-// still write consecutive 16-B words: every wave store is a contiguous, line-aligned 1 KiB.
-struct FlushMap {
-  int t_off;  // row of the tile this thread starts at
-  int p;      // band pair
-  int rpi;    // rows covered per iteration by the workgroup
-  bool on;
-};
-
-template <class S, typename TIO, int T>
-__device__ inline void flush_fused(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int c, int j0,
-                                   const FlushMap& fm, double invmu) {
-  const int nb2 = a.nb >> 1, nz = a.nz;
-  const d2* tile2 = reinterpret_cast<const d2*>(tile);
-  const d2 bc = reinterpret_cast<const d2*>(bandc)[fm.p];
-  for (int t = fm.t_off; t < T; t += fm.rpi) {
-    const int j = j0 + t;
-    if (!fm.on || j >= nz) continue;
-    d2 st[S::NST], o[S::NOUT];
-#pragma unroll
-    for (int q = 0; q < S::NST; ++q) st[q] = tile2[(q * T + t) * nb2 + fm.p];
-    S::emit(rec, nz, j, bc, invmu, st, o);
-#pragma unroll
-    for (int k = 0; k < S::NOUT; ++k) {
-      const int rows = S::out_rows(k, nz);
-      if (j < rows) {
-        typedef TIO vt __attribute__((ext_vector_type(2)));
-        vt v;
-        v.x = (TIO)o[k].x;
-        v.y = (TIO)o[k].y;
-        reinterpret_cast<vt*>(a.o[k])[((long long)c * rows + j) * nb2 + fm.p] = v;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// The segment loops are fully unrolled: the register-resident pairs be[M], bf[M] need static indices (a runtime-indexed
-// array goes to scratch; VGPR-index mode on vector types works but costs ~40 instructions per level, measured).
-template <class S, typename TIO, int M, int T, bool FUSED>
-__device__ __forceinline__ void tri_tile_body(const SolveArgs& a, const TriCfg& cfg, double* lds) {
-  const int nb = a.nb, nz = a.nz;
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int c = blockIdx.x;
-  const double* rec = lds;
-  double* bandc = lds + cfg.off_bc;
-  double* ck = lds + cfg.off_ck + tid;       // [nck][2][nthr]
-  double* tile = lds + cfg.off_tile;         // [NST][T][nb]
-  const int tstride = T * nb;
-  const bool active = tid < nb;
-  const int b = active ? tid : 0;
-  const float inv_nb = 1.0f / (float)nb;
-  const double invmu = rec[S_INVMU];
-  FlushMap fm;
-  {
-    const int nb2 = nb >> 1;
-    fm.rpi = nthr / nb2;  // >= 2 because nthr >= nb
-    fm.t_off = tid / nb2;
-    fm.p = tid - fm.t_off * nb2;
-    fm.on = fm.t_off < fm.rpi;
-  }
-
-  S st;
-  st.template init<TIO>(rec, a, c, b);
-  if (active) bandc[b] = st.band_const();
-  const int K = S::rows(nz);
-
-  // ---- pass 1: forward recurrence, keep the even-row pair of every M-th level ----
-  double e, f;
-  st.first(rec, nz, e, f);
-  ck[0] = e;
-  ck[nthr] = f;
-  for (int k = 0; k + 1 < K; ++k) {
-    st.advance(k, rec, nz, e, f);
-    if ((k + 1) % M == 0) {
-      const int s = (k + 1) / M;
-      ck[(2 * s) * nthr] = e;
-      ck[(2 * s + 1) * nthr] = f;
-    }
-  }
-
-  // ---- pass 2: segments from the top; recompute the segment's pairs into registers, back-substitute, flush ----
-  for (int seg = (K - 1) / M; seg >= 0; --seg) {
-    const int k0 = seg * M;
-    const int kend = min(k0 + M - 1, K - 1);
-    double be[M], bf[M];  // pairs of levels k0 .. k0+M-1 (statically indexed: the loops below are fully unrolled)
-    be[0] = ck[(2 * seg) * nthr];
-    bf[0] = ck[(2 * seg + 1) * nthr];
-#pragma unroll
-    for (int i = 1; i < M; ++i) {
-      be[i] = be[i - 1];
-      bf[i] = bf[i - 1];
-      if (k0 + i <= kend) st.advance(k0 + i - 1, rec, nz, be[i], bf[i]);
-    }
-#pragma unroll
-    for (int i = M - 1; i >= 0; --i) {
-      const int k = k0 + i;
-      if (k <= kend) {
-        double o[S::NST];
-        if (k == K - 1)
-          st.top(rec, nz, be[i], bf[i], o);
-        else
-          st.back(k, rec, nz, be[i], bf[i], o);
-        if (active) {
-#pragma unroll
-          for (int q = 0; q < S::NST; ++q) tile[q * tstride + (i % T) * nb + b] = o[q];
-        }
-      }
-      if (i % T == 0) {  // bottom row of a tile (T divides M, segments start at multiples of M)
-        if (k <= kend) {
-          // LDS-only barriers: __syncthreads() would also drain this wave's global stores (vmcnt(0)) and serialise the
-          // recurrence behind the HBM write round trip of the previous tile
-          lds_barrier();
-          if constexpr (FUSED)
-            flush_fused<S, TIO, T>(a, rec, bandc, tile, c, k, fm, invmu);
-          else
-            flush_arrays<S, TIO, 0>(a, rec, bandc, tile, tstride, c, k, T, invmu, inv_nb, tid, nthr);
-          lds_barrier();
-        }
-      }
-    }
-  }
-}
-
-// S_UNIF columns run the scheme's uniform-dLAI object (UniformOf, tri_schemes.hpp); the flag is per column = per workgroup
-template <class S, typename TIO, int M, int T, int MAXT, bool FUSED>
-__global__ __launch_bounds__(MAXT) void k_tri_tile(SolveArgs a, TriCfg cfg) {
-  static_assert(M % T == 0, "tile height must divide the checkpoint spacing");
-  extern __shared__ double lds[];
-  {
-    const double* src = a.ws + (long long)blockIdx.x * a.reclen;
-    for (int i = threadIdx.x; i < a.reclen; i += blockDim.x) lds[i] = src[i];
-  }
-  __syncthreads();
-  typedef typename UniformOf<S>::type SU;
-  if constexpr (!std::is_same<S, SU>::value) {
-    if (lds[S_UNIF] != 0.0) {
-      tri_tile_body<SU, TIO, M, T, FUSED>(a, cfg, lds);
-      return;
-    }
-  }
-  tri_tile_body<S, TIO, M, T, FUSED>(a, cfg, lds);
-}
-
-template <class S, typename TIO, int M, int T, bool FUSED>
-int launch_mt(const SolveArgs& a, hipStream_t s, int nthr) {
-  const int K = S::rows(a.nz);
-  TriCfg cfg;
-  cfg.T = T;
-  cfg.nck = (K - 1) / M + 1;
-  cfg.off_bc = (a.reclen + 1) & ~1;
-  cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
-  cfg.off_tile = cfg.off_ck + 2 * cfg.nck * nthr;
-  const size_t sh = ((size_t)cfg.off_tile + (size_t)S::NST * T * a.nb) * sizeof(double);
-  if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
-  const void* fn = nthr <= 256 ? (const void*)k_tri_tile<S, TIO, M, T, 256, FUSED> : nthr <= 512 ? (const void*)k_tri_tile<S, TIO, M, T, 512, FUSED>
-                                                                                      : (const void*)k_tri_tile<S, TIO, M, T, 1024, FUSED>;
-  if (sh > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
-    return CRT_ERR_LAUNCH;
-  dim3 grid(a.ncol), block(nthr);
-  if (nthr <= 256)
-    hipLaunchKernelGGL((k_tri_tile<S, TIO, M, T, 256, FUSED>), grid, block, sh, s, a, cfg);
-  else if (nthr <= 512)
-    hipLaunchKernelGGL((k_tri_tile<S, TIO, M, T, 512, FUSED>), grid, block, sh, s, a, cfg);
-  else
-    hipLaunchKernelGGL((k_tri_tile<S, TIO, M, T, 1024, FUSED>), grid, block, sh, s, a, cfg);
-  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
-}
-
-// ------------------------------------------------------------------------------------------
-// Integrated outputs only (IntArgs, crt_internal.hpp): the same checkpointed sweep, but instead of staging and flushing
-// profiles every level's net flux is reduced across the bands with ngroup wave shuffles.
-template <class S, typename TIO, int M>
-__device__ __forceinline__ void tri_int_body(const SolveArgs& a, const IntArgs& ia, int off_ck, int off_int, double* lds) {
-  const int nb = a.nb, nz = a.nz, ng = ia.ngroup;
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
-  const int c = blockIdx.x;
-  const double* rec = lds;
-  double* ck = lds + off_ck + tid;  // [nck][2][nthr]
-  IntLds L;
-  L.part = lds + off_int;
-  L.ends = L.part + (size_t)nz * nwave * INT_MAXG;
-  L.pdr = L.ends + (size_t)2 * nwave * 2 * INT_MAXG;
-  const bool active = tid < nb;
-  const int b = active ? tid : 0;
-  S st;
-  st.template init<TIO>(rec, a, c, b);
-  const double bc = st.band_const();
-  const long long ib = (long long)c * a.col_stride + b;
-  const double leaf_a = 1 - (ldio<TIO>(a.leaf_r, ib) + ldio<TIO>(a.leaf_t, ib));
-  double w[INT_MAXG];
-#pragma unroll
-  for (int g = 0; g < INT_MAXG; ++g) w[g] = (g < ng && active) ? ia.band_w[(long long)g * nb + b] : 0.0;
-#pragma unroll
-  for (int g = 0; g < INT_MAXG; ++g)
-    if (g < ng) {
-      const double t = wave_sum_all(w[g] * leaf_a * bc);
-      if (lane == 0) L.pdr[wave * INT_MAXG + g] = t;
-    }
-  const int K = S::rows(nz);
-  double e, f;
-  st.first(rec, nz, e, f);
-  ck[0] = e;
-  ck[nthr] = f;
-  for (int k = 0; k + 1 < K; ++k) {
-    st.advance(k, rec, nz, e, f);
-    if ((k + 1) % M == 0) {
-      const int sidx = (k + 1) / M;
-      ck[(2 * sidx) * nthr] = e;
-      ck[(2 * sidx + 1) * nthr] = f;
-    }
-  }
-  for (int seg = (K - 1) / M; seg >= 0; --seg) {
-    const int k0 = seg * M;
-    const int kend = min(k0 + M - 1, K - 1);
-    double be[M], bf[M];
-    be[0] = ck[(2 * seg) * nthr];
-    bf[0] = ck[(2 * seg + 1) * nthr];
-#pragma unroll
-    for (int i = 1; i < M; ++i) {
-      be[i] = be[i - 1];
-      bf[i] = bf[i - 1];
-      if (k0 + i <= kend) st.advance(k0 + i - 1, rec, nz, be[i], bf[i]);
-    }
-#pragma unroll
-    for (int i = M - 1; i >= 0; --i) {
-      const int k = k0 + i;
-      if (k <= kend) {
-        double o[S::NST];
-        if (k == K - 1)
-          st.top(rec, nz, be[i], bf[i], o);
-        else
-          st.back(k, rec, nz, be[i], bf[i], o);
-        if (k < nz) int_accumulate<false>(L, nwave, wave, lane, nz, k, ng, w, active, bc * rec[REC_HDR + k], o[0], o[1]);
-      }
-    }
-  }
-  int_finish<false>(L, ia, nwave, nz, c, rec[S_KB]);
-}
-
-template <class S, typename TIO, int M, int MAXT>
-__global__ __launch_bounds__(MAXT) void k_tri_int(SolveArgs a, IntArgs ia, int off_ck, int off_int) {
-  extern __shared__ double lds[];
-  {
-    const double* src = a.ws + (long long)blockIdx.x * a.reclen;
-    for (int i = threadIdx.x; i < a.reclen; i += blockDim.x) lds[i] = src[i];
-  }
-  __syncthreads();
-  typedef typename UniformOf<S>::type SU;
-  if constexpr (!std::is_same<S, SU>::value) {
-    if (lds[S_UNIF] != 0.0) {
-      tri_int_body<SU, TIO, M>(a, ia, off_ck, off_int, lds);
-      return;
-    }
-  }
-  tri_int_body<S, TIO, M>(a, ia, off_ck, off_int, lds);
-}
-
-template <class S, typename TIO, int M>
-int launch_int_m(const SolveArgs& a, const IntArgs& ia, hipStream_t s, int nthr) {
-  const int K = S::rows(a.nz);
-  const int nck = (K - 1) / M + 1;
-  const int off_ck = (a.reclen + 1) & ~1;
-  const int off_int = off_ck + 2 * nck * nthr;
-  const size_t sh = ((size_t)off_int + int_lds_doubles(a.nz, nthr / 64)) * sizeof(double);
-  if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
-  auto go = [&](auto kern) {
-    if (sh > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
-      return (int)CRT_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, ia, off_ck, off_int);
-    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
-  };
-  if (nthr <= 256) return go(k_tri_int<S, TIO, M, 256>);
-  if (nthr <= 512) return go(k_tri_int<S, TIO, M, 512>);
-  return go(k_tri_int<S, TIO, M, 1024>);
-}
-
-template <class S, typename TIO>
-int launch_int_scheme(const SolveArgs& a, const IntArgs& ia, hipStream_t s) {
-  if (a.nb > 1024) return CRT_ERR_UNSUPPORTED;
-  const int nthr = ((a.nb + 63) / 64) * 64;
-  int st = launch_int_m<S, TIO, 8>(a, ia, s, nthr);  // small M: fewer registers, LDS is not the constraint here
-  if (st == CRT_ERR_UNSUPPORTED) st = launch_int_m<S, TIO, 16>(a, ia, s, nthr);
-  return st;
-}
-
-int g_tri_tune[4] = {0, 0, 0, 0};  // [0] force M (8/12/16), [1] force T (4/8)
-
-// instantiated (M, T) pairs
-template <class S, typename TIO, bool FUSED>
-int launch_cfg(const SolveArgs& a, hipStream_t s, int M, int T, int nthr) {
-  if (M == 8 && T == 4) return launch_mt<S, TIO, 8, 4, FUSED>(a, s, nthr);
-  if (M == 8 && T == 8) return launch_mt<S, TIO, 8, 8, FUSED>(a, s, nthr);
-  if (M == 12 && T == 4) return launch_mt<S, TIO, 12, 4, FUSED>(a, s, nthr);
-  if (M == 12 && T == 12) return launch_mt<S, TIO, 12, 12, FUSED>(a, s, nthr);
-  if (M == 16 && T == 4) return launch_mt<S, TIO, 16, 4, FUSED>(a, s, nthr);
-  if (M == 16 && T == 8) return launch_mt<S, TIO, 16, 8, FUSED>(a, s, nthr);
-  return CRT_ERR_UNSUPPORTED;
-}
-
-// ------------------------------------------------------------------------------------------
-// Wave-specialised pipeline.  In k_tri_tile every wave of a workgroup alternates between the recurrence and the flush, and
-// because all workgroups run the same schedule the whole chip alternates with them: HBM idles while the recurrences run
-// and the ALUs idle while the store queues drain (measured: time = store time + compute time, for 1 or 2 workgroups
-// per CU alike).  Here the workgroup carries extra "store waves" that do nothing but flush: the compute waves write
-// tile g into one LDS buffer while the store waves stream tile g-1 out of the other, one LDS-only barrier per tile.
-//   barrier #n : compute waves arrive after completing tile n-1, store waves before reading it; a compute wave writes
-//   tile n+1 (same buffer as n-1) only after barrier #n+1, which the store waves reach after their reads of tile n-1.
-struct PipeCfg {
-  int ncomp;     // compute threads (multiple of 64); threads beyond are store threads
-  int nck;
-  int off_bc, off_ck, off_tile;  // LDS offsets in doubles; tile = [2][NST][T][nb]
-};
-
-template <class S, typename TIO, int M, int T, int RS>
-__device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
-  const int nb = a.nb, nz = a.nz;
-  const int tid = threadIdx.x, nthr = cfg.ncomp;
-  const int c = blockIdx.x;
-  const double* rec = lds;
-  double* bandc = lds + cfg.off_bc;
-  double* ck = lds + cfg.off_ck + tid;  // [nck][2][ncomp]
-  double* tile = lds + cfg.off_tile;
-  const int tstride = T * nb, bstride = S::NST * tstride;
-  const bool active = tid < nb;
-  const int b = active ? tid : 0;
-  S st;
-  st.template init<TIO>(rec, a, c, b);
-  if (active) bandc[b] = st.band_const();
-  const int K = S::rows(nz);
-  double e, f;
-  st.first(rec, nz, e, f);
-  ck[0] = e;
-  ck[nthr] = f;
-  for (int k = 0; k + 1 < K; ++k) {
-    st.advance(k, rec, nz, e, f);
-    if ((k + 1) % M == 0) {
-      const int sidx = (k + 1) / M;
-      ck[(2 * sidx) * nthr] = e;
-      ck[(2 * sidx + 1) * nthr] = f;
-    }
-  }
-  int buf = 0;
-  for (int seg = (K - 1) / M; seg >= 0; --seg) {
-    const int k0 = seg * M;
-    const int kend = min(k0 + M - 1, K - 1);
-    double be[M], bf[M];
-    be[0] = ck[(2 * seg) * nthr];
-    bf[0] = ck[(2 * seg + 1) * nthr];
-#pragma unroll
-    for (int i = 1; i < M; ++i) {
-      be[i] = be[i - 1];
-      bf[i] = bf[i - 1];
-      if (k0 + i <= kend) st.advance(k0 + i - 1, rec, nz, be[i], bf[i]);
-    }
-#pragma unroll
-    for (int i = M - 1; i >= 0; --i) {
-      const int k = k0 + i;
-      if (k <= kend) {
-        double o[S::NST];
-        if (k == K - 1)
-          st.top(rec, nz, be[i], bf[i], o);
-        else
-          st.back(k, rec, nz, be[i], bf[i], o);
-        if (active) {
-#pragma unroll
-          for (int q = 0; q < S::NST; ++q) tile[buf * bstride + q * tstride + (i % T) * nb + b] = o[q];
-        }
-        if (i % T == 0) {  // tile complete: hand it to the store waves
-          lds_barrier();
-          if constexpr (RS > 0)
-            lds_barrier();  // single buffer: wait until the store waves hold the tile in registers
-          else
-            buf ^= 1;
-        }
-      }
-    }
-  }
-}
-
-// RS > 0: ONE LDS tile buffer; the store waves pull the finished tile into registers (RS band pairs x NST staged values per
-// thread), release the buffer with a second barrier and only then issue the stores, so the registers of the store waves
-// play the part of the second buffer.  Halves the tile's LDS -> two workgroups per CU, whose forward sweeps (no stores yet)
-// hide behind each other's flushes.
-template <class S, typename TIO, int M, int T, int RS>
-__device__ __forceinline__ void tri_pipe_store_rs(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
-  const int nb2 = a.nb >> 1, nz = a.nz;
-  const int c = blockIdx.x;
-  const int sid = threadIdx.x - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
-  const double* rec = lds;
-  const d2* bandc2 = reinterpret_cast<const d2*>(lds + cfg.off_bc);
-  const d2* tb = reinterpret_cast<const d2*>(lds + cfg.off_tile);
-  const double invmu = rec[S_INVMU];
-  const int K = S::rows(nz);
-  const int dt = nst / nb2, dp = nst - dt * nb2;
-  const int t0 = sid / nb2, p0 = sid - t0 * nb2;
-  for (int seg = (K - 1) / M; seg >= 0; --seg) {
-    const int k0 = seg * M;
-    const int kend = min(k0 + M - 1, K - 1);
-    for (int i = M - T; i >= 0; i -= T) {
-      const int k = k0 + i;
-      if (k > kend) continue;
-      const int jmax = min(kend, nz - 1);
-      d2 v[RS][S::NST];
-      int tt[RS], pp[RS];
-      lds_barrier();  // tile complete
-      {
-        int t = t0, p = p0;
-#pragma unroll
-        for (int it = 0; it < RS; ++it) {
-          tt[it] = t;
-          pp[it] = p;
-          if (t < T) {
-#pragma unroll
-            for (int q = 0; q < S::NST; ++q) v[it][q] = tb[(q * T + t) * nb2 + p];
-          }
-          p += dp;
-          t += dt;
-          if (p >= nb2) {
-            p -= nb2;
-            ++t;
-          }
-        }
-      }
-      lds_barrier();  // values are in registers (lgkmcnt(0) inside): the compute waves may overwrite the tile
-#pragma unroll
-      for (int it = 0; it < RS; ++it) {
-        __builtin_amdgcn_sched_barrier(0);  // one pair at a time: keeps the emit temporaries of the RS pairs from being live together
-        const int j = k + tt[it];
-        if (tt[it] < T && j <= jmax) {
-          d2 o[S::NOUT];
-          S::emit(rec, nz, j, bandc2[pp[it]], invmu, v[it], o);
-#pragma unroll
-          for (int r = 0; r < S::NOUT; ++r) {
-            const int rows = S::out_rows(r, nz);
-            if (j < rows) {
-              typedef TIO vt __attribute__((ext_vector_type(2)));
-              vt w;
-              w.x = (TIO)o[r].x;
-              w.y = (TIO)o[r].y;
-              // wave-uniform column base (scalar registers) + one 32-bit lane offset shared by all arrays
-              vt* colbase = reinterpret_cast<vt*>(a.o[r]) + (long long)c * rows * nb2;
-              colbase[(unsigned)(j * nb2 + pp[it])] = w;
-            }
-          }
-        }
-      }
-    }
-  }
-}
-
-// any nb / alignment: the generic flat flush of k_tri_tile, run by the store waves on the double-buffered tile
-template <class S, typename TIO, int M, int T>
-__device__ __forceinline__ void tri_pipe_store_generic(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
-  const int nb = a.nb, nz = a.nz;
-  const int c = blockIdx.x;
-  const int sid = threadIdx.x - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
-  const double* rec = lds;
-  const double* bandc = lds + cfg.off_bc;
-  const double* tile = lds + cfg.off_tile;
-  const int tstride = T * nb, bstride = S::NST * tstride;
-  const double invmu = rec[S_INVMU];
-  const float inv_nb = 1.0f / (float)nb;
-  const int K = S::rows(nz);
-  int buf = 0;
-  for (int seg = (K - 1) / M; seg >= 0; --seg) {
-    const int k0 = seg * M;
-    const int kend = min(k0 + M - 1, K - 1);
-    for (int i = M - T; i >= 0; i -= T) {
-      const int k = k0 + i;
-      if (k > kend) continue;
-      lds_barrier();  // tile `buf` is complete
-      flush_arrays<S, TIO, 0>(a, rec, bandc, tile + buf * bstride, tstride, c, k, min(T, kend - k + 1), invmu, inv_nb, sid, nst);
-      buf ^= 1;
-    }
-  }
-}
-
-template <class S, typename TIO, int M, int T>
-__device__ __forceinline__ void tri_pipe_store(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
-  const int nb2 = a.nb >> 1, nz = a.nz;
-  const int c = blockIdx.x;
-  const int sid = threadIdx.x - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
-  const double* rec = lds;
-  const d2* bandc2 = reinterpret_cast<const d2*>(lds + cfg.off_bc);
-  const d2* tile2 = reinterpret_cast<const d2*>(lds + cfg.off_tile);
-  const double invmu = rec[S_INVMU];
-  const int K = S::rows(nz);
-  // thread -> (row, band pair) walk over the T x nb2 pairs of a tile: consecutive threads, consecutive 16-B words
-  const int dt = nst / nb2, dp = nst - dt * nb2;
-  const int t0 = sid / nb2, p0 = sid - t0 * nb2;
-  int buf = 0;
-  for (int seg = (K - 1) / M; seg >= 0; --seg) {
-    const int k0 = seg * M;
-    const int kend = min(k0 + M - 1, K - 1);
-    for (int i = M - T; i >= 0; i -= T) {
-      const int k = k0 + i;
-      if (k > kend) continue;
-      lds_barrier();  // tile `buf` is complete
-      const d2* tb = tile2 + (size_t)buf * (S::NST * T * nb2);
-      const int jmax = min(kend, nz - 1);
-      int t = t0, p = p0;
-      while (t < T) {
-        const int j = k + t;
-        if (j <= jmax) {
-          d2 st[S::NST], o[S::NOUT];
-#pragma unroll
-          for (int q = 0; q < S::NST; ++q) st[q] = tb[(q * T + t) * nb2 + p];
-          S::emit(rec, nz, j, bandc2[p], invmu, st, o);
-#pragma unroll
-          for (int r = 0; r < S::NOUT; ++r) {
-            const int rows = S::out_rows(r, nz);
-            if (j < rows) {
-              typedef TIO vt __attribute__((ext_vector_type(2)));
-              vt v;
-              v.x = (TIO)o[r].x;
-              v.y = (TIO)o[r].y;
-              vt* colbase = reinterpret_cast<vt*>(a.o[r]) + (long long)c * rows * nb2;
-              colbase[(unsigned)(j * nb2 + p)] = v;
-            }
-          }
-        }
-        p += dp;
-        t += dt;
-        if (p >= nb2) {
-          p -= nb2;
-          ++t;
-        }
-      }
-      buf ^= 1;
-    }
-  }
-}
-
-template <class S, typename TIO, int M, int T, int MAXT, int RS>
-__global__ __launch_bounds__(MAXT) void k_tri_pipe(SolveArgs a, PipeCfg cfg) {
-  static_assert(M % T == 0, "tile height must divide the checkpoint spacing");
-  extern __shared__ double lds[];
-  {
-    const double* src = a.ws + (long long)blockIdx.x * a.reclen;
-    for (int i = threadIdx.x; i < a.reclen; i += blockDim.x) lds[i] = src[i];
-  }
-  __syncthreads();
-  if ((int)threadIdx.x >= cfg.ncomp) {
-    if constexpr (RS > 0)
-      tri_pipe_store_rs<S, TIO, M, T, RS>(a, cfg, lds);
-    else if constexpr (RS < 0)
-      tri_pipe_store_generic<S, TIO, M, T>(a, cfg, lds);
-    else
-      tri_pipe_store<S, TIO, M, T>(a, cfg, lds);
-    return;
-  }
-  typedef typename UniformOf<S>::type SU;
-  if constexpr (!std::is_same<S, SU>::value) {
-    if (lds[S_UNIF] != 0.0) {
-      tri_pipe_compute<SU, TIO, M, T, RS>(a, cfg, lds);
-      return;
-    }
-  }
-  tri_pipe_compute<S, TIO, M, T, RS>(a, cfg, lds);
-}
-
-// returns CRT_ERR_UNSUPPORTED when the shape does not fit (caller falls back to k_tri_tile)
-constexpr int PIPE_RS = 4;  // band pairs a store thread holds in the register-staged variant
-
-template <class S, typename TIO, int M, int T>
-int launch_pipe_generic(const SolveArgs& a, hipStream_t s, int nstore_waves) {
-  const int ncomp = ((a.nb + 63) / 64) * 64;
-  const int nthr = ncomp + 64 * nstore_waves;
-  if (nthr > 512) return CRT_ERR_UNSUPPORTED;  // instantiated for narrow spectra only (the odd-nb case that matters: nb = 107)
-  const int K = S::rows(a.nz);
-  PipeCfg cfg;
-  cfg.ncomp = ncomp;
-  cfg.nck = (K - 1) / M + 1;
-  cfg.off_bc = (a.reclen + 1) & ~1;
-  cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
-  cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
-  const size_t sh = ((size_t)cfg.off_tile + (size_t)2 * S::NST * T * a.nb) * sizeof(double);
-  if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
-  auto kern = k_tri_pipe<S, TIO, M, T, 512, -1>;
-  if (sh > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
-    return CRT_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, cfg);
-  return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
-}
-
-template <class S, typename TIO, int M, int T>
-int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves, bool regstage) {
-  const int ncomp = ((a.nb + 63) / 64) * 64;
-  const int nthr = ncomp + 64 * nstore_waves;
-  if (nthr > 1024) return CRT_ERR_UNSUPPORTED;
-  if (regstage && T * (a.nb / 2) > PIPE_RS * 64 * nstore_waves) return CRT_ERR_UNSUPPORTED;
-  const int K = S::rows(a.nz);
-  PipeCfg cfg;
-  cfg.ncomp = ncomp;
-  cfg.nck = (K - 1) / M + 1;
-  cfg.off_bc = (a.reclen + 1) & ~1;
-  cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
-  cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
-  const size_t sh = ((size_t)cfg.off_tile + (size_t)(regstage ? 1 : 2) * S::NST * T * a.nb) * sizeof(double);
-  if (sh > (regstage ? MAX_WG_LDS / 2 : MAX_WG_LDS)) return CRT_ERR_UNSUPPORTED;  // register staging only pays with 2 WG/CU
-  auto go = [&](auto kern) {
-    if (sh > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
-      return (int)CRT_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, cfg);
-    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
-  };
-  if (regstage) return nthr <= 512 ? go(k_tri_pipe<S, TIO, M, T, 512, PIPE_RS>) : go(k_tri_pipe<S, TIO, M, T, 1024, PIPE_RS>);
-  return nthr <= 512 ? go(k_tri_pipe<S, TIO, M, T, 512, 0>) : go(k_tri_pipe<S, TIO, M, T, 1024, 0>);
-}
-
-template <class S, typename TIO>
-int launch_pipe(const SolveArgs& a, hipStream_t s, int M, int T, int nsw, bool regstage) {
-  if (M == 8 && T == 4) return launch_pipe_mt<S, TIO, 8, 4>(a, s, nsw, regstage);
-  if (M == 12 && T == 4) return launch_pipe_mt<S, TIO, 12, 4>(a, s, nsw, regstage);
-  if (M == 16 && T == 4) return launch_pipe_mt<S, TIO, 16, 4>(a, s, nsw, regstage);
-  if (M == 16 && T == 8) return launch_pipe_mt<S, TIO, 16, 8>(a, s, nsw, regstage);
-  return CRT_ERR_UNSUPPORTED;
-}
-
-template <class S, typename TIO>
-int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 64) {
-  done = false;
-  if (a.nb < min_nb || a.nb > 1024) return CRT_OK;  // narrow spectra: the per-wave kernels fill their lanes better
-  const int nthr = ((a.nb + 63) / 64) * 64;
-  const int K = S::rows(a.nz);
-  auto lds_bytes = [&](int M, int T) {
-    const int nck = (K - 1) / M + 1;
-    return ((size_t)a.reclen + a.nb + 4 + 2 * (size_t)nck * nthr + (size_t)S::NST * T * a.nb) * sizeof(double);
-  };
-  // Measured on MI355X at 1e4 x 300 (tools/ab_tri.py, interleaved rounds, fused flush):
-  //   n79 nz=60 : M12/T4 (2 WG/CU) 1.84 ms | M8/T8 2.25 | M16/T4 2.37 | M8/T4 2.28 | per-wave kernel 2.79
-  //   zq  nz=60 : M8/T8 (1 WG/CU) 1.91 ms | M16/T8 1.92 | M12/T4 2.02 | per-wave 2.47
-  //   zq  nz=100: M8/T8 3.11 ms | M16/T8 3.16 | M8/T4 3.18 | M12/T4 3.20 | per-wave 5.15
-  int M = 0, T = 0;
-  const int pref_n79[6][2] = {{12, 4}, {8, 8}, {16, 8}, {8, 4}, {16, 4}, {12, 12}};
-  const int pref_zq[6][2] = {{8, 8}, {16, 8}, {12, 4}, {8, 4}, {16, 4}, {12, 12}};
-  const int (*pref)[2] = S::NOUT == 6 ? pref_n79 : pref_zq;
-  for (int i = 0; i < 6 && !M; ++i) {
-    const size_t need = lds_bytes(pref[i][0], pref[i][1]);
-    // a (M, 4) choice is only worth it when it leaves two workgroups per CU
-    const size_t budget = pref[i][1] == 4 && i == 0 ? 78 * 1024 : MAX_WG_LDS;
-    if (need <= budget) { M = pref[i][0]; T = pref[i][1]; }
-  }
-  if (g_tri_tune[0] > 0) {
-    M = g_tri_tune[0];
-    T = g_tri_tune[1] > 0 ? g_tri_tune[1] : 4;
-    if (lds_bytes(M, T) > MAX_WG_LDS) return CRT_OK;
-  }
-  if (!M) return CRT_OK;
-  // fused flush needs even nb and 16-B aligned output arrays
-  bool fused = (a.nb % 2 == 0);
-  for (int i = 0; i < S::NOUT && fused; ++i)
-    if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) fused = false;
-  // odd nb / unaligned outputs: pipeline with the generic flush.  The per-element flush is too much work for a few store
-  // waves once the spectrum is wide (tools/ab_tri_odd.py, k_tri_tile -> pipeline with 2 store waves: nb=107 n79 1.81 -> 1.90 ms,
-  // zq 2.35 -> 2.29, zq nz=100 3.00 -> 2.22; nb=255 n79 1.60 -> 2.39, zq 2.25 -> 2.86), so only narrow spectra take it
-  // (tune key 10 = 4 forces it for any nb).
-  if (!fused && g_tri_tune[2] != 1 && g_tri_tune[0] == 0 && (nthr <= 128 || g_tri_tune[2] == 4)) {
-    const int nsw = g_tri_tune[3] > 0 ? g_tri_tune[3] : 2;
-    int st = launch_pipe_generic<S, TIO, 12, 4>(a, s, nsw);
-    if (st == CRT_ERR_UNSUPPORTED) st = launch_pipe_generic<S, TIO, 16, 4>(a, s, nsw);
-    if (st != CRT_ERR_UNSUPPORTED) {
-      done = st == CRT_OK;
-      return st;
-    }
-  }
-  if (fused && g_tri_tune[2] != 1) {  // wave-specialised pipeline first (tune key 10 = 1 disables, key 11 = store waves)
-    // Measured on MI355X at 1e4 x 300 (tools/ab_tri.py, profiles/r01/ab_tri_pipe_*.txt; fill probe 6.3-6.8 TB/s):
-    //                best k_tri_tile -> double-buffer pipeline (1 WG/CU) -> register-staged pipeline (2 WG/CU)
-    //   n79 nz=60 :  1.649 ms        -> 1.522 (M12/T4, 4 store waves)    -> 1.384 (M12/T4, 3 store waves) = 0.93 of the fill rate
-    //   zq  nz=60 :  1.852           -> 1.771 (M8/T4, 3)                 -> 1.607 (M12/T4, 3)             = 0.95
-    //   zq  nz=100:  3.115           -> 2.902 (M16/T4, 4)                -> 2.857 (M16/T4, 3)             = 0.93
-    int nsw = g_tri_tune[3] > 0 ? g_tri_tune[3] : 4;
-    if (nthr + 64 * nsw > 1024) nsw = (1024 - nthr) / 64;
-    int st = CRT_ERR_UNSUPPORTED;
-    if (nsw >= 1) {
-      // tune key 10: 0 = automatic, 1 = no pipeline, 2 = double-buffer pipeline only, 3 = register-staged only
-      const bool try_rs = g_tri_tune[2] != 2, try_db = g_tri_tune[2] != 3;
-      // register-staged: 5 compute + 3 store waves = 8 waves per workgroup, two workgroups fill the 16 wave slots of a CU at <= 128 VGPRs
-      const int nsw_rs = g_tri_tune[3] > 0 ? nsw : min(nsw, 3);
-      if (g_tri_tune[0] > 0) {
-        if (try_rs) st = launch_pipe<S, TIO>(a, s, M, T, nsw_rs, true);
-        if (st == CRT_ERR_UNSUPPORTED && try_db) st = launch_pipe<S, TIO>(a, s, M, T, nsw, false);
-      } else {
-        const int pp_n79[3][2] = {{12, 4}, {16, 4}, {8, 4}};
-        const int pp_zq[3][2] = {{8, 4}, {12, 4}, {16, 4}};
-        const int (*pp)[2] = S::NOUT == 6 ? pp_n79 : pp_zq;
-        for (int i = 0; i < 3 && st == CRT_ERR_UNSUPPORTED && try_rs; ++i) st = launch_pipe<S, TIO>(a, s, pp[i][0], pp[i][1], nsw_rs, true);
-        for (int i = 0; i < 3 && st == CRT_ERR_UNSUPPORTED && try_db; ++i) st = launch_pipe<S, TIO>(a, s, pp[i][0], pp[i][1], nsw, false);
-      }
-    }
-    if (st != CRT_ERR_UNSUPPORTED) {
-      done = st == CRT_OK;
-      return st;
-    }
-  }
-  const int st = fused ? launch_cfg<S, TIO, true>(a, s, M, T, nthr) : launch_cfg<S, TIO, false>(a, s, M, T, nthr);
-  if (st == CRT_ERR_UNSUPPORTED) return CRT_OK;
-  done = st == CRT_OK;
-  return st;
-}
-
-}  // namespace
+int g_tri_tune[4] = {0, 0, 0, 0};  // crt_hip_tune keys 8..11, see tri_tile_impl.hpp
 
 void tune_tridiag(int key, int value) {
   if (key >= 0 && key < 4) g_tri_tune[key] = value;
 }
 
 int launch_tridiag_int(int scheme, const SolveArgs& a, const IntArgs& ia, hipStream_t s) {
-  if (scheme == CRT_SCHEME_N79)
-    return a.f32 ? launch_int_scheme<TriN79, float>(a, ia, s) : launch_int_scheme<TriN79, double>(a, ia, s);
-  if (scheme == CRT_SCHEME_ZQ) return a.f32 ? launch_int_scheme<TriZq, float>(a, ia, s) : launch_int_scheme<TriZq, double>(a, ia, s);
+  if (scheme == CRT_SCHEME_N79) return a.f32 ? launch_tri_int_n79_f32(a, ia, s) : launch_tri_int_n79_f64(a, ia, s);
+  if (scheme == CRT_SCHEME_ZQ) return a.f32 ? launch_tri_int_zq_f32(a, ia, s) : launch_tri_int_zq_f64(a, ia, s);
   return CRT_ERR_BAD_ARG;
 }
 
 // returns CRT_OK with done = false when the column-tile kernel does not apply (caller falls back)
 int launch_tridiag_tile(int scheme, const SolveArgs& a, hipStream_t s, bool& done) {
-  if (scheme == CRT_SCHEME_N79) return a.f32 ? launch_scheme<TriN79, float>(a, s, done) : launch_scheme<TriN79, double>(a, s, done);
-  if (scheme == CRT_SCHEME_ZQ) return a.f32 ? launch_scheme<TriZq, float>(a, s, done) : launch_scheme<TriZq, double>(a, s, done);
+  if (scheme == CRT_SCHEME_N79) return a.f32 ? launch_tri_tile_n79_f32(a, s, done) : launch_tri_tile_n79_f64(a, s, done);
+  if (scheme == CRT_SCHEME_ZQ) return a.f32 ? launch_tri_tile_zq_f32(a, s, done) : launch_tri_tile_zq_f64(a, s, done);
   done = false;
   return CRT_ERR_BAD_ARG;
-}
-
-}  // namespace crt
-
-// ------------------------------------------------------------------------------------------
-// zq_pa (crt1d/solvers/_solve_zq_pa.py:24-418): the zq system on a computational grid of M = min(100, nz) equal
-// layers, then linear interpolation of the interface fluxes back to the caller's levels.
-//   step 1: the zq column-tile kernel above runs with nz := M on the K0 record of scheme zq_pa (whose first vector is
-//           the beam fraction per computational layer and whose tau_i / tau_psi are those of LAI/M) and writes only
-//           I_df_d[z] = SWd[z+1], I_df_u[z] = SWu[z], z = 0..M-1, into workspace scratch;
-//   step 2: k_zqpa_interp forms SWd[0] := SWd[1], SWu[M] := SWu[M-1] (:310,335), interpolates and writes the outputs.
-namespace crt {
-namespace {
-
-struct InterpArgs {
-  int ncol, nb, nz, M, reclen;
-  long long col_stride;
-  const double* ws;
-  const double* dnz;  // [ncol][M][nb]  SWd[z+1]
-  const double* upz;  // [ncol][M][nb]  SWu[z]
-  const void* I_dr0;
-  void* o[4];
-};
-
-template <typename TIO>
-__global__ __launch_bounds__(256) void k_zqpa_interp(InterpArgs a) {
-  extern __shared__ double lds[];
-  const int c = blockIdx.x, tid = threadIdx.x;
-  const int nb = a.nb, nz = a.nz, M = a.M;
-  const double* src = a.ws + (long long)c * a.reclen;
-  for (int i = tid; i < a.reclen; i += 256) lds[i] = src[i];
-  __syncthreads();
-  const double* rec = lds;
-  const double invmu = rec[S_INVMU];
-  const double* ekl = rec + REC_HDR + nz;
-  const double* kidx = ekl + nz;
-  const double* wgt = kidx + nz;
-  const long long sb = (long long)c * M * nb;
-  // flat sweep over the column's nz * nb outputs: consecutive threads -> consecutive addresses
-  for (int i = tid; i < nz * nb; i += 256) {
-    const int j = i / nb, b = i - j * nb;
-    const int ka = (int)kidx[j], kb = ka - 1;  // interfaces above / below lai[j] (0 = ground)
-    const double w = wgt[j];
-    // SWd[k] = dnz[max(k,1)-1],  SWu[k] = upz[min(k, M-1)]
-    const double da = a.dnz[sb + (long long)(max(ka, 1) - 1) * nb + b], db = a.dnz[sb + (long long)(max(kb, 1) - 1) * nb + b];
-    const double ua = a.upz[sb + (long long)min(ka, M - 1) * nb + b], ub = a.upz[sb + (long long)min(kb, M - 1) * nb + b];
-    const double dn = da + (db - da) * w;  // :360
-    const double up = ua + (ub - ua) * w;  // :361
-    const double idr = ldio<TIO>(a.I_dr0, (long long)c * a.col_stride + b) * ekl[j];  // :354-355
-    const long long o = (long long)c * nz * nb + i;
-    outp<TIO>(a.o[0])[o] = (TIO)idr;
-    outp<TIO>(a.o[1])[o] = (TIO)dn;
-    outp<TIO>(a.o[2])[o] = (TIO)up;
-    outp<TIO>(a.o[3])[o] = (TIO)(idr * invmu + 2 * up + 2 * dn);  // :412
-  }
-}
-
-}  // namespace
-
-int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s) {
-  if (a.f32) return CRT_ERR_UNSUPPORTED;  // the computational-grid scratch is fp64; f32 storage not wired for zq_pa yet
-  const int M = zqpa_M(a.nz);
-  SolveArgs g = a;  // computational-grid solve: nz := M, outputs := scratch
-  g.nz = M;
-  g.o[0] = scratch;
-  g.o[1] = scratch + (size_t)a.ncol * M * a.nb;
-  for (int i = 2; i < 7; ++i) g.o[i] = nullptr;
-  bool done = false;
-  int st = launch_scheme<TriZqPa, double>(g, s, done, 1);
-  if (st != CRT_OK) return st;
-  if (!done && (st = launch_zqpa_wave(g, s)) != CRT_OK) return st;  // nb > 1024: per-wave kernel (solve_tridiag.hip)
-  InterpArgs ia;
-  ia.ncol = a.ncol;
-  ia.nb = a.nb;
-  ia.nz = a.nz;
-  ia.M = M;
-  ia.reclen = a.reclen;
-  ia.col_stride = a.col_stride;
-  ia.ws = a.ws;
-  ia.dnz = scratch;
-  ia.upz = scratch + (size_t)a.ncol * M * a.nb;
-  ia.I_dr0 = a.I_dr0;
-  for (int i = 0; i < 4; ++i) ia.o[i] = a.o[i];
-  const size_t sh = a.reclen * sizeof(double);
-  if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
-  if (sh > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_zqpa_interp<double>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
-    return CRT_ERR_LAUNCH;
-  hipLaunchKernelGGL((k_zqpa_interp<double>), dim3(a.ncol), dim3(256), sh, s, ia);
-  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 
 }  // namespace crt
