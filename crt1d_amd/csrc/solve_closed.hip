@@ -606,7 +606,7 @@ __global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {
 // the level arithmetic and the flush, and every workgroup on the chip follows the same schedule, so the store queues run
 // dry while the level arithmetic executes (time ~ store time + compute time).  Here `ncomp` compute threads (one per band)
 // fill tile g in one LDS buffer while the remaining "store waves" stream tile g-1 out of the other buffer;
-// one LDS-only barrier per tile (protocol: see k_tri_pipe in solve_tridiag_tile.hip).
+// one LDS-only barrier per tile (protocol: see k_tri_pipe in tri_tile_impl.hpp).
 struct PipeTileCfg {
   int ncomp;    // compute threads (multiple of 64)
   int T;        // levels per tile

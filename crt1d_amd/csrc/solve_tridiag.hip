@@ -180,7 +180,7 @@ int launch_wave(const SolveArgs& a, hipStream_t s) {
 
 template <typename TIO>
 int launch_tridiag_io(int scheme, const SolveArgs& a, hipStream_t s, int force) {
-  if (force != 1) {  // column-tile kernel (solve_tridiag_tile.hip) when it applies; force = 1 keeps the per-wave kernels
+  if (force != 1) {  // column-tile / pipeline kernels (tri_tile_impl.hpp) when they apply; force = 1 keeps the per-wave kernels
     bool done = false;
     const int st = launch_tridiag_tile(scheme, a, s, done);
     if (st != CRT_OK || done) return st;

@@ -1,4 +1,4 @@
-// Scheme objects of the tridiagonal solvers (n79, zq), shared by the column-tile kernel (solve_tridiag_tile.hip) and the
+// Scheme objects of the tridiagonal solvers (n79, zq), shared by the column-tile and pipeline kernels (tri_tile_impl.hpp) and the
 // per-wave fallback kernels (solve_tridiag.hip) so that both produce identical bits.  Not part of the ABI.
 #pragma once
 #include "crt_internal.hpp"
@@ -283,7 +283,7 @@ struct TriZq {
 
 // ------------------------------------------------------------------------------------------
 // zq_pa computational-grid solve (crt1d/solvers/_solve_zq_pa.py:24-418): the zq system with nz := M, only the two
-// single-scattering interface fluxes are kept (see solve_tridiag_tile.hip, launch_zqpa).
+// single-scattering interface fluxes are kept (see tri_zqpa.hip, launch_zqpa).
 struct TriZqPa : TriZq {
   static constexpr int NOUT = 2;
   __host__ __device__ static inline int out_rows(int, int nz) { return nz; }
