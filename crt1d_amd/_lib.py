@@ -93,6 +93,8 @@ EXPORTS = [
     "crt_hip_absorb_f64",
     "crt_hip_smear_tuv_f64",
     "crt_hip_lai_beta_f64",
+    "crt_hip_buffer_alloc",
+    "crt_hip_buffer_free",
     "crt_hip_tune",
     "crt_hip_probe_fill_f64",
     "crt_hip_probe_copy_f64",
@@ -164,6 +166,10 @@ def load():
     lib.crt_hip_smear_tuv_f64.argtypes = [_vp, ctypes.c_int64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp]
     lib.crt_hip_lai_beta_f64.restype = ctypes.c_int
     lib.crt_hip_lai_beta_f64.argtypes = [_vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp]
+    lib.crt_hip_buffer_alloc.restype = ctypes.c_int
+    lib.crt_hip_buffer_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+    lib.crt_hip_buffer_free.restype = ctypes.c_int
+    lib.crt_hip_buffer_free.argtypes = [ctypes.c_void_p]
     lib.crt_hip_tune.restype = None
     lib.crt_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.crt_hip_probe_fill_f64.restype = ctypes.c_int

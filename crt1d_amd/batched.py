@@ -208,11 +208,52 @@ def workspace_bytes(scheme, ncol, nz, nb=1):
     return int(_lib.load().crt_hip_workspace_bytes_nb(_lib.SCHEME_IDS[scheme], ncol, nz, nb))
 
 
-def alloc_outputs(scheme, ncol, nz, nb, device, dtype=torch.float64):
+class _DeviceBuffer:
+    """Owner of one ``crt_hip_buffer_alloc`` allocation; exposes it to torch through ``__cuda_array_interface__`` (the
+    tensor made from it keeps this object, and with it the memory, alive)."""
+
+    def __init__(self, shape, dtype, device):
+        self._lib = _lib.load()
+        self._ptr = ctypes.c_void_p()
+        self._dev = torch.device(device)
+        itemsize = torch.empty((), dtype=dtype).element_size()
+        n = 1
+        for s in shape:
+            n *= int(s)
+        with torch.cuda.device(self._dev):
+            _lib.check(self._lib.crt_hip_buffer_alloc(max(n, 1) * itemsize, ctypes.byref(self._ptr)), "crt_hip_buffer_alloc")
+        self.__cuda_array_interface__ = {
+            "shape": tuple(int(s) for s in shape), "typestr": {torch.float64: "<f8", torch.float32: "<f4"}[dtype],
+            "data": (self._ptr.value, False), "version": 2, "strides": None,
+        }
+
+    def __del__(self):
+        if getattr(self, "_ptr", None) is not None and self._ptr.value:
+            try:
+                torch.cuda.synchronize(self._dev)  # nothing may still be writing into it
+                self._lib.crt_hip_buffer_free(self._ptr)
+            except Exception:  # interpreter shutdown
+                pass
+            self._ptr = None
+
+
+def device_buffer(shape, dtype=torch.float64, device="cuda"):
+    """A tensor backed by 1 GB physical chunks (``crt_hip_buffer_alloc``, include/crt1d_hip.h); falls back to nothing: raises
+    if the virtual-memory API is unavailable."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return torch.as_tensor(_DeviceBuffer(shape, dtype, dev), device=dev)
+
+
+def alloc_outputs(scheme, ncol, nz, nb, device, dtype=torch.float64, chunked=False):
+    """Output arrays of one scheme; ``chunked=True`` backs arrays of at least 64 MB with 1 GB physical chunks."""
     out = {}
     for k in OUT_KEYS[scheme]:
         n = nz - 1 if k in _MID_KEYS.get(scheme, ()) else nz
-        out[k] = torch.empty((ncol, n, nb), dtype=dtype, device=device)
+        shape = (ncol, n, nb)
+        big = ncol * n * nb * (8 if dtype == torch.float64 else 4) >= (64 << 20)
+        out[k] = device_buffer(shape, dtype, device) if (chunked and big) else torch.empty(shape, dtype=dtype, device=device)
     return out
 
 
@@ -278,14 +319,14 @@ class Plan:
         e1.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    def _choose_placement(self, nsets=3, nmix=6, seed=0x5EED):
+    def _choose_placement(self, nsets=4, nmix=6, seed=0x5EED):
         """Pick WHERE the output arrays live.  The solve kernels are HBM-write-bound, and on MI355X the same kernel on the same
         data runs in one of two modes depending on where the driver happened to place the output arrays in HBM: ~0.93 ms or
         ~1.12 ms for 2s at 1e4 x 300 x 60, stable for the life of the allocation, nothing to do with their virtual addresses
         (the slow mode shows twice the DRAM-credit stalls at the L2).  Since a Plan's buffers are
         allocated once and reused, it is worth a fraction of a second: allocate a few candidate sets (each after a random-size
-        pad, which moves where the next allocation lands), time the solve on each, try a few mixes of arrays across sets, keep
-        the fastest and free the rest.  Skipped when the candidates would not fit comfortably in free memory."""
+        pad, which moves where the next allocation lands; every other one built from 1 GB physical chunks), time the solve on each,
+        try a few mixes of arrays across sets, keep the fastest and free the rest.  Skipped when the candidates would not fit comfortably in free memory."""
         import random
 
         dev = self.cols.device
@@ -297,9 +338,13 @@ class Plan:
             rng = random.Random(seed)
             self()  # K0 once: the timings below reuse the column records
             sets, pads = [self.out], []
-            for _ in range(nsets - 1):
+            ncol, nz, nb = self.cols.ncol, self.cols.nz, self.bands.nb
+            for i in range(nsets - 1):
                 pads.append(torch.empty(rng.randrange(1, 150) << 21, dtype=torch.uint8, device=dev))
-                sets.append({k: torch.empty_like(v) for k, v in self.out.items()})
+                try:  # every other candidate is backed by 1 GB physical chunks (crt_hip_buffer_alloc): same two modes, a faster best case
+                    sets.append(alloc_outputs(self.scheme, ncol, nz, nb, dev, self.bands.dtype, chunked=(i % 2 == 0)))
+                except RuntimeError:
+                    sets.append(alloc_outputs(self.scheme, ncol, nz, nb, dev, self.bands.dtype))
             # yardstick: the streaming-fill rate of this device, measured on one of the arrays; a candidate whose outputs are
             # written at >= 95 % of it is in the fast mode and the search stops
             big = max(self.out.values(), key=lambda v: v.numel() * v.element_size())

@@ -227,6 +227,15 @@ int crt_hip_smear_tuv_f64(const double* x, int64_t x_stride, int32_t nx, const d
 int crt_hip_lai_beta_f64(const double* h_c, const double* LAI, const double* h_min, int32_t ncol, int32_t nz, double* lai, double* z,
                          double* lad, crt_stream_t stream);
 
+/*
+ * Device buffers for the output profiles (optional; any device pointer works with the solve entry points).  Built with the HIP
+ * virtual-memory API from 1 GB physical allocations: the solve kernels' store pattern runs 2-3 % faster into them than into
+ * hipMalloc memory of the same region (tools/vmm_bw.hip).  The buffer belongs to the current device; free it with
+ * crt_hip_buffer_free after all work that uses it has completed.  No counterpart in the reference (NumPy owns its arrays).
+ */
+int crt_hip_buffer_alloc(size_t bytes, void** ptr);
+int crt_hip_buffer_free(void* ptr);
+
 /* measurement aid (not for production use): override kernel-selection heuristics, see solve_closed.hip */
 void crt_hip_tune(int key, int value);
 

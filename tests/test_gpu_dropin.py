@@ -386,3 +386,29 @@ def test_plan_placement_auto():
     assert batched.Plan("2s", cols, bands, out=ref.out, placement="auto").placement_report is None  # caller's buffers are kept
     with pytest.raises(ValueError):
         batched.Plan("2s", cols, bands, placement="best")
+
+
+def test_device_buffer_roundtrip():
+    """crt_hip_buffer_alloc / _free behind batched.device_buffer: a normal torch tensor as far as the kernels and torch care."""
+    import gc
+
+    import torch
+
+    from crt1d_amd import batched, synth
+
+    t = batched.device_buffer((3, 5, 7))
+    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.data_ptr() % (2 << 20) == 0
+    t.fill_(2.5)
+    assert float(t.sum()) == 2.5 * 105
+    d = synth.make_columns(2000, 128, 40, seed=2)  # 82 MB per array: above the 64 MB threshold of alloc_outputs(chunked=True)
+    cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
+    out = batched.alloc_outputs("n79", 2000, 40, 128, "cuda", chunked=True)
+    got = batched.Plan("n79", cols, bands, out=out)()
+    ref = batched.Plan("n79", cols, bands)()
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k
+    f32 = batched.device_buffer((4, 4), dtype=torch.float32)
+    assert f32.dtype == torch.float32
+    del t, out, got, f32
+    gc.collect()  # frees the buffers (crt_hip_buffer_free) without error
