@@ -153,8 +153,9 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   const int reclen = rec_len(a.scheme, nz);
   double* rec = a.ws + (long long)c * reclen;
 
+  const double gden = tab ? 0.0 : G_den(kind, param);  // angle-independent part of G, once per thread
   for (int q = tid; q < NQT; q += K0_BLOCK) {
-    const double g = tab ? tab[q] : G_closed(kind, param, qc.cs[q], qc.sn[q]);
+    const double g = tab ? tab[q] : G_eval(kind, param, gden, qc.cs[q], qc.sn[q]);
     kq[q] = g / qc.cs[q];
     pmb[q] = qc.w[q] * qc.cs[q] * qc.sn[q] / g;
   }
@@ -163,11 +164,11 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
     double lo, hi;
     g4_interval(a.mu_s, iv, lo, hi);
     const double p = lo + (qc.gx[i] + 1.0) * (hi - lo) / 2;
-    const double g = tab ? tab[NQT + tid] : G_closed(kind, param, cos(p), sin(p));
+    const double g = tab ? tab[NQT + tid] : G_eval(kind, param, gden, cos(p), sin(p));
     pg[tid] = qc.gw[i] * (hi - lo) / 2 * g * sin(p);
   }
   if (tid < CRT_NQ_9SKY) {
-    const double g = tab ? tab[NQT + NQG + tid] : G_closed(kind, param, qc.cs9[tid], qc.sn9[tid]);
+    const double g = tab ? tab[NQT + NQG + tid] : G_eval(kind, param, gden, qc.cs9[tid], qc.sn9[tid]);
     k9[tid] = g / qc.cs9[tid];
   }
   __syncthreads();
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   if (wave == 0) {
     const double psi = a.psi[c];
     const double cs = cos(psi), sn = sin(psi);
-    const double G = tab ? a.g_at_psi[c] : G_closed(kind, param, cs, sn);
+    const double G = tab ? a.g_at_psi[c] : G_eval(kind, param, gden, cs, sn);
     const double Kb = G / cs;
     // uniform-dlai detection (lets the solve kernels advance exponentials by recurrence)
     const double dl = (lai[0] - lai[nz - 1]) / (nz - 1);

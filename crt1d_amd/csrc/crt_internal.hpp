@@ -103,19 +103,27 @@ __device__ inline double ellipsoidal_p2(double x) {
   return x + asin(e) / e;
 }
 
-__device__ inline double G_closed(int kind, double param, double cs, double sn) {
+// G(psi) = G_eval(kind, param, G_den(kind, param), cos psi, sin psi).  G_den is the part that does not depend on the angle
+// (the ellipsoidal normalisations); K0 evaluates it once per thread and G_eval at each of its quadrature nodes.
+// x^-0.733 as exp(-0.733 log x): ~3 ulp instead of pow's < 1 ulp, a third of its instructions (K0 is bound by exactly these).
+__device__ inline double G_den(int kind, double param) {
+  switch (kind) {
+    case CRT_G_ELLIPSOIDAL: return param == 1.0 ? 0.0 : ellipsoidal_p2(param);
+    case CRT_G_ELLIPSOIDAL_APPROX: return param + 1.774 * exp(-0.733 * log(param + 1.182));
+    default: return 0.0;
+  }
+}
+
+__device__ inline double G_eval(int kind, double param, double den, double cs, double sn) {
   switch (kind) {
     case CRT_G_HORIZONTAL: return cs;
     case CRT_G_SPHERICAL: return 0.5;
     case CRT_G_VERTICAL: return 0.63661977236758134308 * sn;  // 2/pi
     case CRT_G_ELLIPSOIDAL: {
       if (param == 1.0) return 0.5;
-      return sqrt(param * param * cs * cs + sn * sn) / ellipsoidal_p2(param);
+      return sqrt(param * param * cs * cs + sn * sn) / den;
     }
-    case CRT_G_ELLIPSOIDAL_APPROX: {
-      double p2 = param + 1.774 * pow(param + 1.182, -0.733);
-      return sqrt(param * param * cs * cs + sn * sn) / p2;
-    }
+    case CRT_G_ELLIPSOIDAL_APPROX: return sqrt(param * param * cs * cs + sn * sn) / den;
     case CRT_G_ELLIPSOIDAL_APPROX_BONAN: {
       double chil = fmin(fmax(param, -0.4), 0.6);
       double phi1 = 0.5 - 0.633 * chil - 0.330 * chil * chil;
@@ -124,6 +132,10 @@ __device__ inline double G_closed(int kind, double param, double cs, double sn) 
     }
     default: return 0.0 / 0.0;
   }
+}
+
+__device__ inline double G_closed(int kind, double param, double cs, double sn) {
+  return G_eval(kind, param, G_den(kind, param), cs, sn);
 }
 
 // ------------------------------------------------------------------------------------------
