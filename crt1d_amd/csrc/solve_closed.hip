@@ -611,7 +611,6 @@ struct PipeTileCfg {
   int ncomp;    // compute threads (multiple of 64)
   int T;        // levels per tile
   int rec_dbl;  // doubles reserved for the staged column record
-  int mode;     // experiment switch (tune key 5): 1 = nontemporal stores, 2 = array-major flush order
 };
 
 template <class S, typename TIO, int MAXT, bool FUSED>
@@ -690,20 +689,6 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
       const int Tc = min(T, nz - j0);
       lds_barrier();  // tile `buf` is complete
       const vt* tv = reinterpret_cast<const vt*>(tile + buf * bufrun);
-      if (cfg.mode >= 2) {  // experiment: array-major (mode 2) / one array per store wave (mode 3) instead of interleaving the arrays
-        const int n = Tc * nbv;  // vectors per array in this tile (rows are adjacent in memory: one flat run)
-        const long long g0 = ((long long)c * nz + j0) * nbv;
-        if (cfg.mode == 2) {
-          for (int k = 0; k < S::NARR; ++k)
-            for (int i = sid; i < n; i += nst) reinterpret_cast<vt*>(a.o[k])[g0 + i] = tv[(k * colrun) / VW + i];
-        } else {
-          const int w = sid >> 6, nw = nst >> 6, l = sid & 63;
-          for (int k = w; k < S::NARR; k += nw)
-            for (int i = l; i < n; i += 64) reinterpret_cast<vt*>(a.o[k])[g0 + i] = tv[(k * colrun) / VW + i];
-        }
-        buf ^= 1;
-        continue;
-      }
       int t = t0, p = p0;
       while (t < Tc) {
         const long long go = ((long long)c * nz + j0 + t) * nbv + p;
@@ -711,12 +696,7 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
 #pragma unroll
         for (int k = 0; k < S::NARR; ++k) v[k] = tv[(k * colrun + t * nb) / VW + p];
 #pragma unroll
-        for (int k = 0; k < S::NARR; ++k) {
-          if (cfg.mode == 1)
-            __builtin_nontemporal_store(v[k], reinterpret_cast<vt*>(a.o[k]) + go);
-          else
-            reinterpret_cast<vt*>(a.o[k])[go] = v[k];
-        }
+        for (int k = 0; k < S::NARR; ++k) reinterpret_cast<vt*>(a.o[k])[go] = v[k];
         p += dp;
         t += dt;
         if (p >= nbv) {
@@ -798,7 +778,6 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
     pc.ncomp = pcomp;
     pc.T = Tp;
     pc.rec_dbl = (a.reclen + 1) & ~1;
-    pc.mode = g_tune[5];
     const size_t psh = pc.rec_dbl * sizeof(double) + 2 * plevel * Tp;
     if (nsw >= 1 && Tp >= 2 && psh <= 160 * 1024 && (fused ? (2 * plevel * Ta <= target || g_tune[4] > 0) : true)) {
       const int pthr = pcomp + 64 * nsw;

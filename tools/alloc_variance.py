@@ -1,4 +1,5 @@
-"""Does the solve kernel's speed depend on WHERE its output arrays live?  One process, the same kernel and inputs, output
+"""(The flush-order / nontemporal variants this tool once compared -- profiles/r01/alloc_variance.txt -- made no difference and
+were removed from the kernel.)  Does the solve kernel's speed depend on WHERE its output arrays live?  One process, the same kernel and inputs, output
 arrays re-allocated several ways: fresh torch allocations (previous ones kept alive), and slices of one slab with a skew
 of k * skew_bytes between consecutive arrays."""
 import os
@@ -42,7 +43,4 @@ for trial in range(6):
     p = batched.Plan(scheme, cols, bands, out=out, workspace=base.workspace)
     lib = _lib.load()
     t = timeit(p)
-    lib.crt_hip_tune(5, 2); t_am = timeit(p); lib.crt_hip_tune(5, 0)
-    lib.crt_hip_tune(5, 3); t_aw = timeit(p); lib.crt_hip_tune(5, 0)
-    lib.crt_hip_tune(5, 3); lib.crt_hip_tune(3, 4); t_aw4 = timeit(p); lib.crt_hip_tune(5, 0); lib.crt_hip_tune(3, 0)
-    print(f"  trial {trial}: pipe {t:.4f} ms  array-major {t_am:.4f}  array-per-wave(3) {t_aw:.4f}  array-per-wave(4) {t_aw4:.4f}   " + " ".join(f"{(v.data_ptr() >> 21) & 0x3ff:03x}" for v in out.values()), flush=True)
+    print(f"  trial {trial}: {t:.4f} ms   " + " ".join(f"{(v.data_ptr() >> 21) & 0x3ff:03x}" for v in out.values()), flush=True)
