@@ -747,9 +747,9 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 64
     if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) fused = false;
   // odd nb / unaligned outputs: pipeline with the generic flush.  The per-element flush is too much work for a few store
   // waves once the spectrum is wide (tools/ab_tri_odd.py, k_tri_tile -> pipeline with 2 store waves: nb=107 n79 1.81 -> 1.90 ms,
-  // zq 2.35 -> 2.29, zq nz=100 3.00 -> 2.22; nb=255 n79 1.60 -> 2.39, zq 2.25 -> 2.86), so only narrow spectra take it
-  // (tune key 10 = 4 forces it for any nb).
-  if (!fused && g_tri_tune[2] != 1 && g_tri_tune[0] == 0 && (nthr <= 128 || g_tri_tune[2] == 4)) {
+  // zq 2.35 -> 2.29, zq nz=100 3.00 -> 2.22; nb=255 n79 1.60 -> 2.39, zq 2.25 -> 2.86), so only zq on narrow spectra takes it
+  // (tune key 10 = 4 forces it for any scheme and nb).
+  if (!fused && g_tri_tune[2] != 1 && g_tri_tune[0] == 0 && ((nthr <= 128 && S::NOUT == 7) || g_tri_tune[2] == 4)) {
     const int nsw = g_tri_tune[3] > 0 ? g_tri_tune[3] : 2;
     int st = launch_pipe_generic<S, TIO, 12, 4>(a, s, nsw);
     if (st == CRT_ERR_UNSUPPORTED) st = launch_pipe_generic<S, TIO, 16, 4>(a, s, nsw);
