@@ -627,8 +627,10 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
   }
   __syncthreads();
   const double* rec = lds;
-  TIO* tile = reinterpret_cast<TIO*>(lds + cfg.rec_dbl);  // [2][NARR][T][nb]
-  const int colrun = T * nb, bufrun = S::NARR * colrun;
+  // [2][NARR][HEAD + T * nb]; HEAD = one 128-B line of head-room in front of every array's tile (generic flush only, see below)
+  constexpr int HEAD = FUSED ? 0 : 128 / (int)sizeof(TIO);
+  TIO* tile = reinterpret_cast<TIO*>(lds + cfg.rec_dbl) + HEAD;
+  const int colrun = HEAD + T * nb, bufrun = S::NARR * colrun;
   if (tid < cfg.ncomp) {
     // ---- compute role ----
     const bool active = tid < nb;
@@ -651,21 +653,38 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
       buf ^= 1;
     }
   } else if constexpr (!FUSED) {
-    // ---- store role, any nb / alignment: per array one flat run of Tc * nb elements (head up to the next 16-B boundary of
-    // the destination, 16-B vectors, tail), as k_tile's generic flush ----
+    // ---- store role, any nb / alignment.  A column is one flat run of nz * nb elements per array, so a round need not stop at a
+    // level boundary: it writes every 128-B line that is complete so far.  The part-line behind the last complete line is
+    // copied into the head-room in front of the OTHER buffer's tile (memory the compute waves never touch), where the next
+    // round finds it directly in front of its own data: every round flushes one contiguous LDS range into whole lines, and
+    // only the first and the last line of a column can be partial (2 of ~400 at nb = 107, instead of 2 per tile).
+    constexpr int LINE = 128 / (int)sizeof(TIO);
     const int sid = tid - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
+    const long long col0 = (long long)c * nz * nb;
+    int F[S::NARR];  // elements of this column already flushed, per array (the arrays may be aligned differently)
+#pragma unroll
+    for (int k = 0; k < S::NARR; ++k) F[k] = 0;
     int buf = 0;
     for (int j0 = 0; j0 < nz; j0 += T) {
       const int Tc = min(T, nz - j0);
       lds_barrier();  // tile `buf` is complete
-      const int n = Tc * nb;
+      const int t0e = j0 * nb;          // first element of this tile
+      const int avail = t0e + Tc * nb;  // elements of the column computed so far
+      const bool last = j0 + Tc >= nz;
+#pragma unroll
       for (int k = 0; k < S::NARR; ++k) {
-        TIO* g = outp<TIO>(a.o[k]) + ((long long)c * nz + j0) * nb;
-        const TIO* src = tile + buf * bufrun + k * colrun;
-        int mis = (int)(((16 - (reinterpret_cast<uintptr_t>(g) & 15)) & 15) / sizeof(TIO));
+        TIO* gk = outp<TIO>(a.o[k]) + col0;
+        const int f = F[k];
+        const TIO* src = tile + buf * bufrun + k * colrun - (t0e - f);  // element e of the column sits at src[e - f]
+        int end = avail;
+        if (!last) end -= (int)((reinterpret_cast<uintptr_t>(gk + avail) / sizeof(TIO)) % LINE);  // end of the last complete line
+        if (end < f) end = f;
+        const int n = end - f;
+        TIO* g = gk + f;
+        int mis = (int)(((16 - (reinterpret_cast<uintptr_t>(g) & 15)) & 15) / sizeof(TIO));  // non-zero at the column start only
         if (mis > n) mis = n;
         const int nvec = (n - mis) / VW;
-        const int tail = (n - mis) - nvec * VW;
+        const int tail = (n - mis) - nvec * VW;  // non-zero at the column end only
         vt* gv = reinterpret_cast<vt*>(g + mis);
         for (int i = sid; i < nvec; i += nst) {
           vt v;
@@ -675,6 +694,10 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
         }
         if (sid < mis) g[sid] = src[sid];
         if (sid < tail) g[mis + nvec * VW + sid] = src[mis + nvec * VW + sid];
+        // park the part-line [end, avail) in front of the other buffer's tile of this array
+        const int npark = avail - end;
+        if (sid < npark) tile[(buf ^ 1) * bufrun + k * colrun - npark + sid] = src[n + sid];
+        F[k] = end;
       }
       buf ^= 1;
     }
@@ -770,7 +793,11 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
     // Longer tiles lose: T=11 at nb=128 leaves one workgroup per CU, 1.5 ms.
     size_t budget = target;
     if (S::HEAVY_INIT && 2 * plevel * 4 <= 40 * 1024) budget = 40 * 1024;
-    const int Tmax = (int)std::min<size_t>(8, budget / (2 * plevel));
+    // generic flush: whole lines whatever T is, so narrow spectra take short tiles and four or five workgroups per CU
+    // (3e4 x 107 x 60, k_tile -> T=8 -> T=4: 2s 1.268 -> 1.285 -> 1.085 ms, bl 1.174 -> 1.136 -> 1.066, g77 2.174 -> 1.957 -> 1.861)
+    if (!fused && pcomp <= 128 && budget > 32 * 1024) budget = 32 * 1024;
+    int Tmax = (int)std::min<size_t>(8, budget / (2 * plevel));
+    if (Tmax < 4 && 2 * plevel * 4 <= target) Tmax = 4;  // not below 4 levels while two workgroups still fit (g77 at nb = 107: T=2 1.96 ms, T=4 1.87)
     int Tp = Ta <= Tmax ? (Tmax / Ta) * Ta : Tmax;
     if (g_tune[4] > 0) Tp = g_tune[4];
     if (Tp > a.nz) Tp = a.nz;
@@ -778,7 +805,8 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
     pc.ncomp = pcomp;
     pc.T = Tp;
     pc.rec_dbl = (a.reclen + 1) & ~1;
-    const size_t psh = pc.rec_dbl * sizeof(double) + 2 * plevel * Tp;
+    // two tile buffers (the generic flush adds one line of head-room per array and buffer)
+    const size_t psh = pc.rec_dbl * sizeof(double) + 2 * plevel * Tp + (fused ? 0 : 2 * S::NARR * 128);
     if (nsw >= 1 && Tp >= 2 && psh <= 160 * 1024 && (fused ? (2 * plevel * Ta <= target || g_tune[4] > 0) : true)) {
       const int pthr = pcomp + 64 * nsw;
       auto gop = [&](auto kern) {
