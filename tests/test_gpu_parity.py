@@ -252,7 +252,8 @@ def test_error_conventions(torch_cuda):
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)
-@pytest.mark.parametrize("shape", [(1, 1, 2), (2, 5, 3), (1, 2151, 60), (2, 1025, 20), (2, 40, 400), (1, 8, 3000), (70000, 1, 5)])
+@pytest.mark.parametrize("shape", [(1, 1, 2), (2, 5, 3), (1, 2151, 60), (2, 1025, 20), (2, 40, 400), (1, 40, 400), (3, 70, 512), (1, 8, 3000),
+                                   (70000, 1, 5)])
 def test_extreme_shapes(torch_cuda, oracle, scheme, shape):
     """Shapes outside the tuned kernels' range: nb > 1024 (no column-tile kernel), nz far beyond the LDS sweep state
     (per-wave kernel parks the forward pairs in its own output rows), nz = 2, single band, very many columns."""
