@@ -91,6 +91,7 @@ EXPORTS = [
     "crt_hip_absorb_bandsum_f64",
     "crt_hip_integrated_f64",
     "crt_hip_absorb_f64",
+    "crt_hip_tau_d_f64",
     "crt_hip_smear_tuv_f64",
     "crt_hip_lai_beta_f64",
     "crt_hip_buffer_alloc",
@@ -162,6 +163,8 @@ def load():
     ]
     lib.crt_hip_absorb_f64.restype = ctypes.c_int
     lib.crt_hip_absorb_f64.argtypes = [ctypes.POINTER(CrtColumns), ctypes.POINTER(CrtBands), _vp, _vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp]
+    lib.crt_hip_tau_d_f64.restype = ctypes.c_int
+    lib.crt_hip_tau_d_f64.argtypes = [_vp, _vp, ctypes.c_int64, ctypes.c_int32, _vp, _vp]
     lib.crt_hip_smear_tuv_f64.restype = ctypes.c_int
     lib.crt_hip_smear_tuv_f64.argtypes = [_vp, ctypes.c_int64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp]
     lib.crt_hip_lai_beta_f64.restype = ctypes.c_int

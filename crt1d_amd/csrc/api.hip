@@ -441,6 +441,13 @@ int crt_hip_absorb_f64(const crt_columns* cols, const crt_bands* bands, const do
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 
+int crt_hip_tau_d_f64(const double* kb_nodes, const double* L, int64_t n, int32_t method, double* out, crt_stream_t stream) {
+  if (!kb_nodes || !L || !out || n < 0) return CRT_ERR_BAD_ARG;
+  if (method != CRT_TAU_D_QUAD && method != CRT_TAU_D_9SKY) return CRT_ERR_BAD_ARG;  // ValueError, common.py:78
+  if (n == 0) return CRT_OK;
+  return crt::launch_tau_d(kb_nodes, L, (long long)n, method, out, static_cast<hipStream_t>(stream));
+}
+
 void crt_hip_tune(int key, int value) {
   if (key >= 8)
     tune_tridiag(key - 8, value);

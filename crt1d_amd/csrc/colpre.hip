@@ -363,7 +363,28 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   }
 }
 
+// tau_d for arbitrary LAI values from K_b sampled at the library's nodes (common.py:30-87 `tau_df_fn`)
+__global__ __launch_bounds__(256) void k_tau_d(const double* __restrict__ kb_nodes, const double* __restrict__ L, long long n, int method,
+                                                double* __restrict__ out) {
+  __shared__ double kq[NQT];
+  __shared__ double k9[CRT_NQ_9SKY];
+  for (int q = threadIdx.x; q < NQT; q += blockDim.x) kq[q] = kb_nodes[q];
+  if (threadIdx.x < CRT_NQ_9SKY) k9[threadIdx.x] = kb_nodes[NQT + NQG + threadIdx.x];
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = method == CRT_TAU_D_9SKY ? tau_d_9sky(k9, L[i]) : tau_d_quad(kq, L[i]);
+}
+
 }  // namespace
+
+int launch_tau_d(const double* kb_nodes, const double* L, long long n, int method, double* out, hipStream_t s) {
+  const int st = init_quadrature(s);
+  if (st != CRT_OK) return st;
+  const long long nblk = (n + 255) / 256;
+  if (nblk > 0x7fffffffLL) return CRT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_tau_d, dim3((unsigned)nblk), dim3(256), 0, s, kb_nodes, L, n, method, out);
+  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+}
 
 void host_quad_nodes(double mu_s, double* psi_nodes) {
   std::call_once(h_once, build_host_tables);

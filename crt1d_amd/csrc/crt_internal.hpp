@@ -361,6 +361,7 @@ int launch_colpre(const ColArgs& a, hipStream_t s);
 int launch_closed(int scheme, const SolveArgs& a, hipStream_t s, int force);
 int launch_tridiag(int scheme, const SolveArgs& a, hipStream_t s, int force);
 int init_quadrature(hipStream_t s);
+int launch_tau_d(const double* kb_nodes, const double* L, long long n, int method, double* out, hipStream_t s);
 void tune_closed(int key, int value);
 void tune_tridiag(int key, int value);
 int launch_tridiag_tile(int scheme, const SolveArgs& a, hipStream_t s, bool& done);

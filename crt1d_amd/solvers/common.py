@@ -31,6 +31,40 @@ class KbFunction:
         return self.G_fn(psi) / np.cos(psi)
 
 
+def tau_b_fn(K_b_fn, psi, lai):
+    """Direct-beam transmittance ``exp(-K_b(psi) lai)`` (``crt1d/solvers/common.py:11-27``); a one-line closed form, evaluated
+    where the arguments live."""
+    return np.exp(-K_b_fn(psi) * lai)
+
+
+def tau_df_fn(K_b_fn, lai, *, method="quad"):
+    """Diffuse transmittance of foliage with LAI ``lai`` (scalar or array), drop-in for ``crt1d/solvers/common.py:56-87``.
+    ``K_b_fn`` is sampled at the library's quadrature angles and the integral is formed on the device
+    (``crt_hip_tau_d_f64``: fixed 96-node rule for 'quad', the reference's nine angles for '9sky')."""
+    import torch
+
+    if method not in _lib.TAU_D_METHODS:
+        raise ValueError("invalid `method`. Valid options are 'quad' and '9sky'.")  # common.py:78
+    lib = _lib.load()
+    nodes = _lib.quad_nodes()
+    kb = np.ascontiguousarray(_sample(K_b_fn, nodes))
+    L = np.atleast_1d(np.asarray(lai, dtype=np.float64))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    kb_d, L_d = torch.as_tensor(kb).to(dev), torch.as_tensor(np.ascontiguousarray(L.reshape(-1))).to(dev)
+    out = torch.empty_like(L_d)
+    with torch.cuda.device(dev):
+        st = lib.crt_hip_tau_d_f64(kb_d.data_ptr(), L_d.data_ptr(), L_d.numel(), _lib.TAU_D_METHODS[method], out.data_ptr(),
+                                   torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(st, "crt_hip_tau_d_f64")
+    res = out.cpu().numpy().reshape(L.shape)
+    return float(res[0]) if np.isscalar(lai) else res
+
+
+def K_df_fn(K_b_fn, lai_tot, **kwargs):
+    """``K_d = -ln(tau_d(LAI)) / LAI`` (``crt1d/solvers/common.py:90-95``)."""
+    return -np.log(tau_df_fn(K_b_fn, lai_tot, **kwargs)) / lai_tot
+
+
 def _sample(fn, psi):
     """Evaluate a user callable on an array of angles; falls back to a scalar loop."""
     try:

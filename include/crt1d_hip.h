@@ -210,6 +210,14 @@ int crt_hip_absorb_f64(const crt_columns* cols, const crt_bands* bands, const do
                        const double* I_df_u, double* const* out7, double* laim, double* f_slm, crt_stream_t stream);
 
 /*
+ * tau_d(L) = 2 int_0^{pi/2} exp(-K_b(psi) L) sin(psi) cos(psi) dpsi for n values of L: crt1d/solvers/common.py:56-87 `tau_df_fn`
+ * (`_tau_df_fn_scalar` :30-37 with the library's fixed 96-node rule instead of QUADPACK, `_tau_df_fn_scalar_9sky` :40-53
+ * unchanged).  kb_nodes[CRT_NQ] = K_b at the angles of crt_hip_quad_nodes() (device memory, like L and out).  The solvers get the
+ * same numbers from their K0 kernel; this entry point serves callers of `tau_df_fn` / `K_df_fn` (:90-95).
+ */
+int crt_hip_tau_d_f64(const double* kb_nodes, const double* L, int64_t n, int32_t method, double* out, crt_stream_t stream);
+
+/*
  * Input side, batched.
  *
  * crt_hip_smear_tuv_f64 replaces crt1d/spectra.py:260-300 `smear_tuv(x, y, bins)` (per-bin kernel `_smear_tuv_1`,

@@ -20,6 +20,7 @@ g4_ragged    12 synthetic columns x 10 bands x 40 levels, NON-uniform dLAI (expo
 g5_4s_tight  default case, 4s with solve_bvp tol 1e-11 (the reference's stock tol is 1e-6)
 g7_options   mu_s in {0.501, 0.33998}; G_fn in {spherical, horizontal, vertical, ellipsoidal x in {0.5,1,2}, bonan}
 g8_leaf_area reference leaf_area.distribute_lai_beta(h_c, LAI, n, h_min=...) for 8 canopies (lai, lad, z)
+g9_common    reference solvers.common: tau_b_fn, tau_df_fn ('quad' and '9sky'), K_df_fn for 5 leaf-angle functions
 """
 
 import argparse
@@ -248,6 +249,25 @@ def g8(lar, out):
     print("wrote", out / "g8_leaf_area.npz")
 
 
+def g9(la, out):
+    """solvers/common.py:11-95 -- row a7 of the scope table."""
+    com = importlib.import_module("crt1d.solvers.common")
+    lai = np.r_[1e-3, 0.01, 0.1, 0.37, 1.0, 2.5, 4.0, 8.0]
+    gfs = {"spherical": la.G_spherical, "horizontal": la.G_horizontal, "vertical": la.G_vertical,
+           "ellipsoidal_x2": lambda p: la.G_ellipsoidal(p, 2.0), "ellipsoidal_approx_x0.96": lambda p: la.G_ellipsoidal_approx(p, 0.9632)}
+    d = {"lai": lai, "psi": np.array(0.35)}
+    for name, G in gfs.items():
+        K = lambda p, G=G: G(p) / np.cos(p)  # noqa: E731
+        d[f"{name}__tau_b"] = com.tau_b_fn(K, 0.35, lai)
+        d[f"{name}__tau_d_quad"] = com.tau_df_fn(K, lai, method="quad")
+        d[f"{name}__tau_d_9sky"] = com.tau_df_fn(K, lai, method="9sky")
+        d[f"{name}__K_d_quad"] = np.array(com.K_df_fn(K, 4.0))
+        d[f"{name}__K_d_9sky"] = np.array(com.K_df_fn(K, 4.0, method="9sky"))
+        d[f"{name}__tau_d_quad_scalar"] = np.array(com.tau_df_fn(K, 2.5))
+    np.savez_compressed(out / "g9_common.npz", meta=np.array(str(META)), **d)
+    print("wrote", out / "g9_common.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(REPO / "tests" / "golden"))
@@ -289,6 +309,8 @@ def main():
         g7(la, lar, sol, out)
     if want("g8"):
         g8(lar, out)
+    if want("g9"):
+        g9(la, out)
 
 
 if __name__ == "__main__":

@@ -412,3 +412,28 @@ def test_device_buffer_roundtrip():
     assert f32.dtype == torch.float32
     del t, out, got, f32
     gc.collect()  # frees the buffers (crt_hip_buffer_free) without error
+
+
+def test_common_tau_functions_vs_reference():
+    """Row a7 as public API: tau_b_fn, tau_df_fn ('quad' / '9sky'), K_df_fn of crt1d.solvers.common (golden g9_common.npz from the
+    reference).  '9sky' involves no quadrature: 1e-13; 'quad' is bounded by the reference's QUADPACK error (<= 2e-7 here)."""
+    from crt1d_amd import leaf_angle
+    from crt1d_amd.solvers import common
+
+    g = load_golden("g9_common")
+    lai = g["lai"]
+    gfs = {"spherical": leaf_angle.G_spherical, "horizontal": leaf_angle.G_horizontal, "vertical": leaf_angle.G_vertical,
+           "ellipsoidal_x2": lambda p: leaf_angle.G_ellipsoidal(p, 2.0),
+           "ellipsoidal_approx_x0.96": lambda p: leaf_angle.G_ellipsoidal_approx(p, 0.9632)}
+    for name, G in gfs.items():
+        K = lambda p, G=G: G(p) / np.cos(p)  # noqa: E731  (a plain lambda, as the reference's Model builds it)
+        np.testing.assert_allclose(common.tau_b_fn(K, 0.35, lai), g[f"{name}__tau_b"], rtol=1e-15)
+        np.testing.assert_allclose(common.tau_df_fn(K, lai, method="9sky"), g[f"{name}__tau_d_9sky"], rtol=1e-13, err_msg=name)
+        np.testing.assert_allclose(common.tau_df_fn(K, lai, method="quad"), g[f"{name}__tau_d_quad"], rtol=2e-7, err_msg=name)
+        np.testing.assert_allclose(common.tau_df_fn(K, lai), g[f"{name}__tau_d_quad"], rtol=2e-7)  # default method
+        s = common.tau_df_fn(K, 2.5)
+        assert isinstance(s, float) and s == pytest.approx(float(g[f"{name}__tau_d_quad_scalar"]), rel=2e-7)
+        assert common.K_df_fn(K, 4.0) == pytest.approx(float(g[f"{name}__K_d_quad"]), rel=2e-7)
+        assert common.K_df_fn(K, 4.0, method="9sky") == pytest.approx(float(g[f"{name}__K_d_9sky"]), rel=1e-13)
+    with pytest.raises(ValueError):
+        common.tau_df_fn(lambda p: 0.5 / np.cos(p), lai, method="simpson")

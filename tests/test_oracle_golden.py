@@ -189,3 +189,14 @@ def test_distribute_lai_beta_vs_reference(oracle):
         assert np.array_equal(lai, g[f"c{i}__lai"])
         np.testing.assert_allclose(z, g[f"c{i}__z"], rtol=1e-14)
         np.testing.assert_allclose(lad, g[f"c{i}__lad"], rtol=1e-12, atol=1e-300)
+
+
+def test_tau_d_vs_reference_common(oracle):
+    """oracle.tau_d (fixed-node rule / 9sky) against the reference's tau_df_fn (tests/golden/g9_common.npz)."""
+    g = load_golden("g9_common")
+    kinds = {"spherical": (1, 0.0), "horizontal": (0, 0.0), "vertical": (2, 0.0), "ellipsoidal_x2": (3, 2.0), "ellipsoidal_approx_x0.96": (4, 0.9632)}
+    for name, (kind, param) in kinds.items():
+        cols = oracle.Columns([0.35], np.array([[1.0, 0.0]]), g_kind=[kind], g_param=[param])
+        np.testing.assert_allclose(oracle.tau_d(cols, g["lai"][None], method="9sky")[0], g[f"{name}__tau_d_9sky"], rtol=1e-13)
+        # 'quad': the reference's QUADPACK result carries its own error (up to ~3e-8, vertical leaves at small LAI)
+        np.testing.assert_allclose(oracle.tau_d(cols, g["lai"][None], method="quad")[0], g[f"{name}__tau_d_quad"], rtol=2e-7)
