@@ -11,7 +11,7 @@ for scheme, ncol, nb, nz in [("n79", 30000, 107, 60), ("zq", 30000, 107, 60), ("
     cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
     plan = batched.Plan(scheme, cols, bands)
     plan(); torch.cuda.synchronize()
-    variants = {"tile": (1, 0), "pipe s1": (0, 1), "pipe s2": (0, 2), "pipe s3": (0, 3)}
+    variants = {"tile": (1, 0), "pipe s1": (4, 1), "pipe s2": (4, 2), "pipe s3": (4, 3)}
     res = {k: [] for k in variants}
     for rnd in range(4):
         for name, (k10, k11) in variants.items():
