@@ -346,7 +346,7 @@ class Plan:
                 except RuntimeError:
                     sets.append(alloc_outputs(self.scheme, ncol, nz, nb, dev, self.bands.dtype))
             # yardstick: the streaming-fill rate of this device, measured on one of the arrays; a candidate whose outputs are
-            # written at >= 95 % of it is in the fast mode and the search stops
+            # written faster than 1.02 x that rate ends the search early; otherwise all candidates (~10 timings, ~40 ms) are tried
             big = max(self.out.values(), key=lambda v: v.numel() * v.element_size())
             nfill = (big.numel() * big.element_size() // 16) * 2  # whole 16-B vectors, counted in doubles
             st = torch.cuda.current_stream(dev)
@@ -358,7 +358,7 @@ class Plan:
             e1.record(st)
             e1.synchronize()
             fill_bytes_per_ms = 2 * nfill * 8 / e0.elapsed_time(e1)
-            good_ms = total / (0.95 * fill_bytes_per_ms)
+            good_ms = total / (1.02 * fill_bytes_per_ms)  # (the best placements beat the grid-stride fill probe by a few per cent)
             best, tbest, tworst, tried = None, float("inf"), 0.0, 0
             keys = list(self.out)
             cands = list(sets) + [None] * nmix  # None = a random mix of arrays across the sets
@@ -373,6 +373,27 @@ class Plan:
                     best, tbest = cand, t
                 if tbest <= good_ms:
                     break
+            # nothing near the fill rate: every region tried so far is a slow one.  Jump further: sets allocated behind multi-GB
+            # pads land in other physical regions (bounded by a quarter of the free memory)
+            ok_ms = total / (0.93 * fill_bytes_per_ms)
+            for i, pad_gb in enumerate((3, 6, 12, 20, 32, 48)):
+                if tbest <= ok_ms:
+                    break
+                free, _ = torch.cuda.mem_get_info(dev)
+                if (pad_gb << 30) + total > free // 4:
+                    break
+                pads.append(torch.empty(pad_gb << 30, dtype=torch.uint8, device=dev))
+                try:
+                    cand = alloc_outputs(self.scheme, ncol, nz, nb, dev, self.bands.dtype, chunked=(i % 2 == 0))
+                except RuntimeError:
+                    cand = alloc_outputs(self.scheme, ncol, nz, nb, dev, self.bands.dtype)
+                sets.append(cand)
+                self._point_at(cand)
+                t = self._time_ms()
+                tried += 1
+                tworst = max(tworst, t)
+                if t < tbest:
+                    best, tbest = cand, t
             self._point_at(best)
             self.placement_report = {"candidates_timed": tried, "best_ms": tbest, "worst_ms": tworst, "fill_rate_ms": total / fill_bytes_per_ms}
             del sets, pads
