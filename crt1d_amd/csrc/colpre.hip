@@ -114,6 +114,8 @@ __host__ __device__ inline void g4_interval(double mu_s, int iv, double& lo, dou
 
 constexpr int K0_BLOCK = 128;
 constexpr int BL_UNIF_MAX_NZ = 512;
+constexpr int BL_CHUNK = 16;
+static_assert(K0_BLOCK == 8 * BL_CHUNK && CRT_NQ_TAU % 8 == 0, "bl chunk reduction layout");
 
 __device__ inline double tau_d_quad(const double* kq, double L) {
   double s = 0.0;
@@ -141,7 +143,12 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   __shared__ double sh_kb, sh_dlm, sh_dl, sh_tdu;
   __shared__ int sh_unif;
   __shared__ double xis[104];  // zq_pa: cumulative LAI of the computational interfaces
-  __shared__ double bl_part[K0_BLOCK / 64][BL_UNIF_MAX_NZ];  // bl, equal dLAI: per-wave partial tau_d sums of every level
+  // bl only (dynamic, so that the other schemes keep 16 workgroups per CU): the 96 quadrature terms of 16 levels, the sums
+  // over groups of 12 nodes, tau_d of every level
+  extern __shared__ double bl_lds[];
+  double* bl_terms = bl_lds;
+  double* bl_gsum = bl_terms + NQT * (BL_CHUNK + 1);
+  double* bl_td = bl_gsum + 8 * BL_CHUNK;
 
   const int c = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -285,7 +292,10 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   }
   // bl on an equal-dLAI column: tau_d is needed at every level L_j = (nz-1-j) dl.  Instead of 96 exponentials per level
   // (the kernel's whole cost: 5760 fp64 exps per column), thread q carries E_q^m = exp(-K_q dl)^m down the levels by one
-  // multiplication per level (drift <= nz ulp) and the 96 terms of a level are summed with DPP reductions.
+  // multiplication per level (drift <= nz ulp).  The 96 terms of a level are summed through LDS, 16 levels at a time:
+  // thread q writes its 16 terms (row stride 17: conflict-free both ways), thread (g, jj) adds the 12 nodes of group g for
+  // level jj, the first 16 threads add the 8 group sums.  (A wave reduction per level -- 60 x DPP -- cost as much as the
+  // exponentials it replaced.)
   const bool blu = a.scheme == CRT_SCHEME_BL && sh_unif != 0 && nz <= BL_UNIF_MAX_NZ;
   if (blu) {
     const double dl = sh_dl;
@@ -293,12 +303,31 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
     const double E = on ? exp(-kq[on ? tid : 0] * dl) : 0.0;
     const double w = on ? qc.w2sc[tid] : 0.0;
     double P = 1.0;  // level nz-1: L = 0
-    for (int j = nz - 1; j >= 0; --j) {
-      const double t = wave_sum_lane63(w * P);
-      if (lane == 63) bl_part[wave][j] = t;
-      P *= E;
+    for (int jtop = nz - 1; jtop >= 0; jtop -= BL_CHUNK) {  // levels jtop, jtop-1, ... (chunk position jj <-> level jtop - jj)
+      if (on) {
+#pragma unroll
+        for (int jj = 0; jj < BL_CHUNK; ++jj) {
+          bl_terms[tid * (BL_CHUNK + 1) + jj] = w * P;
+          P *= E;
+        }
+      }
+      __syncthreads();
+      {
+        const int jj = tid & (BL_CHUNK - 1), g = tid / BL_CHUNK;  // 128 threads = 8 groups x 16 levels
+        double acc = 0.0;
+        for (int q = g * (NQT / 8); q < (g + 1) * (NQT / 8); ++q) acc += bl_terms[q * (BL_CHUNK + 1) + jj];
+        bl_gsum[g * BL_CHUNK + jj] = acc;
+      }
+      __syncthreads();
+      if (tid < BL_CHUNK && jtop - tid >= 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += bl_gsum[g * BL_CHUNK + tid];
+        bl_td[jtop - tid] = t;
+      }
+      // (bl_terms / bl_gsum are rewritten only after the next chunk's first barrier resp. after its second one)
+      __syncthreads();
     }
-    __syncthreads();
   }
   double* v = rec + REC_HDR;
   for (int j = tid; j < nz; j += K0_BLOCK) {
@@ -328,7 +357,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
       case CRT_SCHEME_BL:
         v[j] = L;
         v[nz + j] = ekl;
-        v[2 * nz + j] = blu ? bl_part[0][j] + bl_part[1][j] : tau_d_quad(kq, L);  // _solve_bl.py:35-37
+        v[2 * nz + j] = blu ? bl_td[j] : tau_d_quad(kq, L);  // _solve_bl.py:35-37
         break;
       case CRT_SCHEME_N79: {
         v[j] = ekl;  // tbcum  _solve_n79.py:46
@@ -416,7 +445,8 @@ int init_quadrature(hipStream_t s) {
 int launch_colpre(const ColArgs& a, hipStream_t s) {
   int st = init_quadrature(s);
   if (st != CRT_OK) return st;
-  hipLaunchKernelGGL(k_colpre, dim3(a.ncol), dim3(K0_BLOCK), 0, s, a);
+  const size_t dyn = a.scheme == CRT_SCHEME_BL ? (NQT * (BL_CHUNK + 1) + 8 * BL_CHUNK + BL_UNIF_MAX_NZ) * sizeof(double) : 0;
+  hipLaunchKernelGGL(k_colpre, dim3(a.ncol), dim3(K0_BLOCK), dyn, s, a);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 
