@@ -319,7 +319,7 @@ class Plan:
         e1.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    def _choose_placement(self, nsets=4, nmix=6, seed=0x5EED):
+    def _choose_placement(self, nsets=4, nmix=12, seed=0x5EED):
         """Pick WHERE the output arrays live.  The solve kernels are HBM-write-bound, and on MI355X the same kernel on the same
         data runs in one of two modes depending on where the driver happened to place the output arrays in HBM: ~0.93 ms or
         ~1.12 ms for 2s at 1e4 x 300 x 60, stable for the life of the allocation, nothing to do with their virtual addresses
@@ -360,13 +360,16 @@ class Plan:
             fill_bytes_per_ms = 2 * nfill * 8 / e0.elapsed_time(e1)
             good_ms = total / (1.02 * fill_bytes_per_ms)  # (the best placements beat the grid-stride fill probe by a few per cent)
             best, tbest, tworst, tried = None, float("inf"), 0.0, 0
+            trials = []  # (what, ms) in the order tried
             keys = list(self.out)
             cands = list(sets) + [None] * nmix  # None = a random mix of arrays across the sets
-            for cand in cands:
+            for ci, cand in enumerate(cands):
+                what = "torch" if ci == 0 else ("chunked" if ci % 2 == 1 else "torch+pad") if ci < nsets else "mix"
                 if cand is None:
                     cand = {k: sets[rng.randrange(nsets)][k] for k in keys}
                 self._point_at(cand)
                 t = self._time_ms()
+                trials.append((what, round(t, 4)))
                 tried += 1
                 tworst = max(tworst, t)
                 if t < tbest:
@@ -390,12 +393,14 @@ class Plan:
                 sets.append(cand)
                 self._point_at(cand)
                 t = self._time_ms()
+                trials.append((f"{'chunked' if i % 2 == 0 else 'torch'}+{pad_gb}GB", round(t, 4)))
                 tried += 1
                 tworst = max(tworst, t)
                 if t < tbest:
                     best, tbest = cand, t
             self._point_at(best)
-            self.placement_report = {"candidates_timed": tried, "best_ms": tbest, "worst_ms": tworst, "fill_rate_ms": total / fill_bytes_per_ms}
+            self.placement_report = {"candidates_timed": tried, "best_ms": tbest, "worst_ms": tworst, "fill_rate_ms": total / fill_bytes_per_ms,
+                                     "trials": trials}
             del sets, pads
             torch.cuda.empty_cache()
 
