@@ -380,7 +380,7 @@ class Plan:
             # pads land in other physical regions (bounded by a quarter of the free memory)
             ok_ms = total / (0.93 * fill_bytes_per_ms)
             for i, pad_gb in enumerate((3, 6, 12, 20, 32, 48)):
-                if tbest <= ok_ms:
+                if tbest <= ok_ms or tbest < 0.95 * tworst:  # near the fill rate, or the candidates differ (a kernel that is not store-bound)
                     break
                 free, _ = torch.cuda.mem_get_info(dev)
                 if (pad_gb << 30) + total > free // 4:

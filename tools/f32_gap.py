@@ -8,6 +8,7 @@ for name, dd in (("f64", d), ("f32", d32)):
     cols, bands = batched.Columns.from_host(dd), batched.Bands.from_host(dd)
     plan = batched.Plan("2s", cols, bands, placement="auto")
     st = torch.cuda.current_stream()
+    print(name, plan.placement_report)
     for flags, what in ((0, "K0+solve"), (_lib.FLAG_SKIP_PRECOMPUTE, "solve only")):
         for _ in range(5): plan(flags=flags)
         torch.cuda.synchronize(); t0 = time.perf_counter()
