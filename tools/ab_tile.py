@@ -12,12 +12,13 @@ plan = batched.Plan(scheme, cols, bands)
 lib = _lib.load()
 # tune keys: 0 = LDS target bytes, 1 = force T (k_tile), 2 = flags (bit1 generic flush, bit2 no pipeline), 3 = store waves, 4 = pipeline T
 variants = {
-    "pipe fused T=4 s3": {0: 78 * 1024, 1: 0, 2: 0, 3: 3, 4: 4},
-    "pipe generic flush T=4 s3": {0: 78 * 1024, 1: 0, 2: 2, 3: 3, 4: 4},
-    "pipe generic flush T=4 s2": {0: 78 * 1024, 1: 0, 2: 2, 3: 2, 4: 4},
-    "pipe generic flush T=4 s4": {0: 78 * 1024, 1: 0, 2: 2, 3: 4, 4: 4},
-    "tile T=8 fused": {0: 78 * 1024, 1: 8, 2: 4, 3: 0, 4: 0},
-    "tile T=8 generic flush": {0: 78 * 1024, 1: 8, 2: 4 | 2, 3: 0, 4: 0},
+    "pipe fused T=4 s3 (default, K0 separate)": {0: 78 * 1024, 1: 0, 2: 16, 3: 3, 4: 4},
+    "pipe generic T=4 s3": {0: 78 * 1024, 1: 0, 2: 2 | 16, 3: 3, 4: 4},
+    "pipe generic T=3 s3": {0: 78 * 1024, 1: 0, 2: 2 | 16, 3: 3, 4: 3},
+    "pipe generic T=2 s3": {0: 78 * 1024, 1: 0, 2: 2 | 16, 3: 3, 4: 2},
+    "pipe generic T=2 s2": {0: 78 * 1024, 1: 0, 2: 2 | 16, 3: 2, 4: 2},
+    "pipe generic T=2 s4": {0: 78 * 1024, 1: 0, 2: 2 | 16, 3: 4, 4: 2},
+    "pipe generic T=1 s3": {0: 78 * 1024, 1: 0, 2: 2 | 16, 3: 3, 4: 1},
 }
 res = {k: [] for k in variants}
 plan(); torch.cuda.synchronize()  # K0 once: the timed launches below skip the precompute and reuse this workspace
