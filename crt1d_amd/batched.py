@@ -379,8 +379,8 @@ class Plan:
             # nothing near the fill rate: every region tried so far is a slow one.  Jump further: sets allocated behind multi-GB
             # pads land in other physical regions (bounded by a quarter of the free memory)
             ok_ms = total / (0.93 * fill_bytes_per_ms)
-            for i, pad_gb in enumerate((3, 6, 12, 20, 32, 48)):
-                if tbest <= ok_ms or tbest < 0.95 * tworst:  # near the fill rate, or the candidates differ (a kernel that is not store-bound)
+            for i, pad_gb in enumerate((3, 6, 12, 20, 32, 48, 64)):
+                if tbest <= ok_ms:
                     break
                 free, _ = torch.cuda.mem_get_info(dev)
                 if (pad_gb << 30) + total > free // 4:

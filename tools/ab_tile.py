@@ -12,13 +12,13 @@ plan = batched.Plan(scheme, cols, bands)
 lib = _lib.load()
 # tune keys: 0 = LDS target bytes, 1 = force T (k_tile), 2 = flags (bit1 generic flush, bit2 no pipeline), 3 = store waves, 4 = pipeline T
 variants = {
-    "pipe fused T=4 s3 (default, K0 separate)": {0: 78 * 1024, 1: 0, 2: 16, 3: 3, 4: 4},
-    "pipe generic T=4 s3": {0: 78 * 1024, 1: 0, 2: 2 | 16, 3: 3, 4: 4},
-    "pipe generic T=3 s3": {0: 78 * 1024, 1: 0, 2: 2 | 16, 3: 3, 4: 3},
-    "pipe generic T=2 s3": {0: 78 * 1024, 1: 0, 2: 2 | 16, 3: 3, 4: 2},
-    "pipe generic T=2 s2": {0: 78 * 1024, 1: 0, 2: 2 | 16, 3: 2, 4: 2},
-    "pipe generic T=2 s4": {0: 78 * 1024, 1: 0, 2: 2 | 16, 3: 4, 4: 2},
-    "pipe generic T=1 s3": {0: 78 * 1024, 1: 0, 2: 2 | 16, 3: 3, 4: 1},
+    "pipe T=4 s3 (2 WG/CU, default)": {0: 78 * 1024, 1: 0, 2: 0, 3: 3, 4: 4},
+    "pipe T=8 s2 (1 WG/CU)": {0: 78 * 1024, 1: 0, 2: 0, 3: 2, 4: 8},
+    "pipe T=8 s3 (1 WG/CU)": {0: 78 * 1024, 1: 0, 2: 0, 3: 3, 4: 8},
+    "pipe T=8 s4 (1 WG/CU)": {0: 78 * 1024, 1: 0, 2: 0, 3: 4, 4: 8},
+    "pipe T=8 s6 (1 WG/CU)": {0: 78 * 1024, 1: 0, 2: 0, 3: 6, 4: 8},
+    "pipe T=8 s8 (1 WG/CU)": {0: 78 * 1024, 1: 0, 2: 0, 3: 8, 4: 8},
+    "pipe T=4 s5 (2 WG/CU)": {0: 78 * 1024, 1: 0, 2: 0, 3: 5, 4: 4},
 }
 res = {k: [] for k in variants}
 plan(); torch.cuda.synchronize()  # K0 once: the timed launches below skip the precompute and reuse this workspace
