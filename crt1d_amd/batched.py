@@ -376,28 +376,34 @@ class Plan:
                     best, tbest = cand, t
                 if tbest <= good_ms:
                     break
-            # nothing near the fill rate: every region tried so far is a slow one.  Jump further: sets allocated behind multi-GB
-            # pads land in other physical regions (bounded by a quarter of the free memory)
+            # nothing near the fill rate: every region tried so far is a slow one.  Jump further: behind a multi-GB pad, two fresh
+            # sets and a few mixes of their arrays land in other physical regions (bounded by a quarter of the free memory)
             ok_ms = total / (0.93 * fill_bytes_per_ms)
-            for i, pad_gb in enumerate((3, 6, 12, 20, 32, 48, 64)):
+            for pad_gb in (8, 16, 32, 48):
                 if tbest <= ok_ms:
                     break
                 free, _ = torch.cuda.mem_get_info(dev)
-                if (pad_gb << 30) + total > free // 4:
+                if (pad_gb << 30) + 2 * total > free // 4:
                     break
                 pads.append(torch.empty(pad_gb << 30, dtype=torch.uint8, device=dev))
-                try:
-                    cand = alloc_outputs(self.scheme, ncol, nz, nb, dev, self.bands.dtype, chunked=(i % 2 == 0))
-                except RuntimeError:
-                    cand = alloc_outputs(self.scheme, ncol, nz, nb, dev, self.bands.dtype)
-                sets.append(cand)
-                self._point_at(cand)
-                t = self._time_ms()
-                trials.append((f"{'chunked' if i % 2 == 0 else 'torch'}+{pad_gb}GB", round(t, 4)))
-                tried += 1
-                tworst = max(tworst, t)
-                if t < tbest:
-                    best, tbest = cand, t
+                far = []
+                for chunked in (False, True):
+                    try:
+                        far.append(alloc_outputs(self.scheme, ncol, nz, nb, dev, self.bands.dtype, chunked=chunked))
+                    except RuntimeError:
+                        far.append(alloc_outputs(self.scheme, ncol, nz, nb, dev, self.bands.dtype))
+                sets.extend(far)
+                for j in range(6):
+                    cand = far[j] if j < 2 else {k: far[rng.randrange(2)][k] for k in keys}
+                    self._point_at(cand)
+                    t = self._time_ms()
+                    trials.append((f"+{pad_gb}GB {'torch' if j == 0 else 'chunked' if j == 1 else 'mix'}", round(t, 4)))
+                    tried += 1
+                    tworst = max(tworst, t)
+                    if t < tbest:
+                        best, tbest = cand, t
+                    if tbest <= ok_ms:
+                        break
             self._point_at(best)
             self.placement_report = {"candidates_timed": tried, "best_ms": tbest, "worst_ms": tworst, "fill_rate_ms": total / fill_bytes_per_ms,
                                      "trials": trials}
