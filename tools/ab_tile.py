@@ -8,17 +8,16 @@ scheme = sys.argv[1] if len(sys.argv) > 1 else "2s"
 ncol, nb, nz = 10000, 300, 60
 d = synth.make_columns(ncol, nb, nz)
 cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
-plan = batched.Plan(scheme, cols, bands)
+plan = batched.Plan(scheme, cols, bands, placement="auto")
 lib = _lib.load()
 # tune keys: 0 = LDS target bytes, 1 = force T (k_tile), 2 = flags (bit1 generic flush, bit2 no pipeline), 3 = store waves, 4 = pipeline T
 variants = {
-    "pipe T=4 s3 (2 WG/CU, default)": {0: 78 * 1024, 1: 0, 2: 0, 3: 3, 4: 4},
-    "pipe T=8 s2 (1 WG/CU)": {0: 78 * 1024, 1: 0, 2: 0, 3: 2, 4: 8},
-    "pipe T=8 s3 (1 WG/CU)": {0: 78 * 1024, 1: 0, 2: 0, 3: 3, 4: 8},
-    "pipe T=8 s4 (1 WG/CU)": {0: 78 * 1024, 1: 0, 2: 0, 3: 4, 4: 8},
-    "pipe T=8 s6 (1 WG/CU)": {0: 78 * 1024, 1: 0, 2: 0, 3: 6, 4: 8},
-    "pipe T=8 s8 (1 WG/CU)": {0: 78 * 1024, 1: 0, 2: 0, 3: 8, 4: 8},
-    "pipe T=4 s5 (2 WG/CU)": {0: 78 * 1024, 1: 0, 2: 0, 3: 5, 4: 4},
+    "k_pipe (default)": {0: 78 * 1024, 1: 0, 2: 0, 3: 0, 4: 0, 6: 0},
+    "k_pipe_p persistent": {0: 78 * 1024, 1: 0, 2: 32, 3: 0, 4: 0, 6: 0},
+    "k_pipe_p persistent s4": {0: 78 * 1024, 1: 0, 2: 32, 3: 4, 4: 0, 6: 0},
+    "k_pipe_p persistent s2": {0: 78 * 1024, 1: 0, 2: 32, 3: 2, 4: 0, 6: 0},
+    "k_pipe_p persistent, 2x workgroups": {0: 78 * 1024, 1: 0, 2: 32, 3: 0, 4: 0, 6: 2},
+    "k_pipe_p persistent, T=8 (1 WG/CU)": {0: 78 * 1024, 1: 0, 2: 32, 3: 0, 4: 8, 6: 0},
 }
 res = {k: [] for k in variants}
 plan(); torch.cuda.synchronize()  # K0 once: the timed launches below skip the precompute and reuse this workspace
