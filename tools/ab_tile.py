@@ -7,17 +7,22 @@ from crt1d_amd import _lib, batched, synth
 scheme = sys.argv[1] if len(sys.argv) > 1 else "2s"
 ncol, nb, nz = 10000, 300, 60
 d = synth.make_columns(ncol, nb, nz)
+if len(sys.argv) > 2 and sys.argv[2] == "f32":
+    import numpy as np
+    d = {k: (v.astype(np.float32) if k in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r") else v) for k, v in d.items()}
 cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
 plan = batched.Plan(scheme, cols, bands, placement="auto")
 lib = _lib.load()
 # tune keys: 0 = LDS target bytes, 1 = force T (k_tile), 2 = flags (bit1 generic flush, bit2 no pipeline), 3 = store waves, 4 = pipeline T
 variants = {
-    "k_pipe (default)": {0: 78 * 1024, 1: 0, 2: 0, 3: 0, 4: 0, 6: 0},
-    "k_pipe_p persistent": {0: 78 * 1024, 1: 0, 2: 32, 3: 0, 4: 0, 6: 0},
-    "k_pipe_p persistent s4": {0: 78 * 1024, 1: 0, 2: 32, 3: 4, 4: 0, 6: 0},
-    "k_pipe_p persistent s2": {0: 78 * 1024, 1: 0, 2: 32, 3: 2, 4: 0, 6: 0},
-    "k_pipe_p persistent, 2x workgroups": {0: 78 * 1024, 1: 0, 2: 32, 3: 0, 4: 0, 6: 2},
-    "k_pipe_p persistent, T=8 (1 WG/CU)": {0: 78 * 1024, 1: 0, 2: 32, 3: 0, 4: 8, 6: 0},
+    "k_pipe default": {0: 78 * 1024, 1: 0, 2: 0, 3: 0, 4: 0},
+    "T=4 s3": {0: 78 * 1024, 1: 0, 2: 0, 3: 3, 4: 4},
+    "T=4 s2": {0: 78 * 1024, 1: 0, 2: 0, 3: 2, 4: 4},
+    "T=8 s2": {0: 78 * 1024, 1: 0, 2: 0, 3: 2, 4: 8},
+    "T=8 s4": {0: 78 * 1024, 1: 0, 2: 0, 3: 4, 4: 8},
+    "T=16 s3": {0: 78 * 1024, 1: 0, 2: 0, 3: 3, 4: 16},
+    "k_tile T=8": {0: 78 * 1024, 1: 8, 2: 4, 3: 0, 4: 0},
+    "k_tile T=16": {0: 78 * 1024, 1: 16, 2: 4, 3: 0, 4: 0},
 }
 res = {k: [] for k in variants}
 plan(); torch.cuda.synchronize()  # K0 once: the timed launches below skip the precompute and reuse this workspace
