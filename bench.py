@@ -38,7 +38,7 @@ N_IO = {  # scheme: (n_in, n_full, n_mid)
 }
 # dominant kernel per scheme as rocprofv3 names it (template arguments abbreviated)
 KERNEL_NAMES = {"2s": "k_pipe<Sch2s>", "4s": "k_pipe<Sch4s>", "bl": "k_pipe<SchBl>", "g77": "k_tile<SchG77<false>>",
-                "bf": "k_tile<SchG77<true>>", "n79": "k_tri_pipe<TriN79>", "zq": "k_tri_pipe<TriZq>", "zq_pa": "k_tri_pipe<TriZqPa> (+ k_zqpa_interp)"}
+                "bf": "k_tile<SchG77<true>>", "n79": "k_tri_pipe<TriN79>", "zq": "k_tri_pipe<TriZq>", "zq_pa": "k_zqpa_pipe (grid solve + interpolation in one kernel)"}
 
 
 def bytes_per_solve(scheme, nz, s=8):

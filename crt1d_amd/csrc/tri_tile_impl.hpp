@@ -401,9 +401,12 @@ struct PipeCfg {
   int ncomp;     // compute threads (multiple of 64); threads beyond are store threads
   int nck;
   int off_bc, off_ck, off_tile;  // LDS offsets in doubles; tile = [2][NST][T][nb]
+  // zq_pa with the interpolation fused into the store waves (tri_zqpa.hip): the caller's level count and output arrays
+  int nz_out, off_halo;
+  void* out[4];
 };
 
-template <class S, typename TIO, int M, int T, int RS>
+template <class S, typename TIO, int M, int T, int RS, int NSTG = S::NST>
 __device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
   const int nb = a.nb, nz = a.nz;
   const int tid = threadIdx.x, nthr = cfg.ncomp;
@@ -412,7 +415,7 @@ __device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeC
   double* bandc = lds + cfg.off_bc;
   double* ck = lds + cfg.off_ck + tid;  // [nck][2][ncomp]
   double* tile = lds + cfg.off_tile;
-  const int tstride = T * nb, bstride = S::NST * tstride;
+  const int tstride = T * nb, bstride = NSTG * tstride;  // NSTG: staged arrays kept in the tile (the first NSTG of NST)
   const bool active = tid < nb;
   const int b = active ? tid : 0;
   S st;
@@ -455,7 +458,7 @@ __device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeC
           st.back(k, rec, nz, be[i], bf[i], o);
         if (active) {
 #pragma unroll
-          for (int q = 0; q < S::NST; ++q) tile[buf * bstride + q * tstride + (i % T) * nb + b] = o[q];
+          for (int q = 0; q < NSTG; ++q) tile[buf * bstride + q * tstride + (i % T) * nb + b] = o[q];
         }
         if (i % T == 0) {  // tile complete: hand it to the store waves
           lds_barrier();

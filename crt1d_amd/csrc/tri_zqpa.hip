@@ -53,10 +53,163 @@ __global__ __launch_bounds__(256) void k_zqpa_interp(InterpArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// One kernel, no scratch: the pipeline's compute waves solve the computational grid (tile by tile, from the top), its store
+// waves interpolate to the caller's levels and write the four profiles.  Both grids are ordered in LAI, so each round can
+// emit a contiguous range of output levels: level j needs the computational rows max(ka-2, 0) .. min(ka, Mg-1), ka = kidx[j]
+// (k_zqpa_interp's index arithmetic), i.e. it is complete once the tile holding row max(ka-2, 0) has arrived; the one or two
+// rows above the tile that it may also need are the two lowest rows of the previous tile, kept in a small halo buffer.
+// Same expressions as k_zqpa_interp -> bitwise the same profiles, 5.8 GB less HBM traffic of 11.5 GB at 1e4 x 300 x 60.
+template <int M, int T>
+__device__ __forceinline__ void zqpa_pipe_store(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
+  static_assert(T >= 2, "the halo holds the two lowest rows of a tile");
+  const int nb2 = a.nb >> 1, Mg = a.nz, nzo = cfg.nz_out;
+  const int c = blockIdx.x;
+  const int sid = threadIdx.x - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
+  const double* rec = lds;
+  const double invmu = rec[S_INVMU];
+  const double* ekl = rec + REC_HDR + nzo;
+  const double* kidx = ekl + nzo;
+  const double* wgt = kidx + nzo;
+  const d2* bandc2 = reinterpret_cast<const d2*>(lds + cfg.off_bc);  // I_dr0 of the band pair
+  const d2* tile2 = reinterpret_cast<const d2*>(lds + cfg.off_tile);  // [2 buffers][2 arrays: dn, up][T][nb2]
+  d2* halo2 = reinterpret_cast<d2*>(lds + cfg.off_halo);              // [2 parities][dn(ktop), up(ktop), up(ktop+1)][nb2]
+  const int K = Mg + 1;
+  int buf = 0, g = 0, jhi = nzo;
+  for (int seg = (K - 1) / M; seg >= 0; --seg) {
+    const int k0 = seg * M;
+    const int kend = min(k0 + M - 1, K - 1);
+    for (int i = M - T; i >= 0; i -= T) {
+      const int k = k0 + i;
+      if (k > kend) continue;
+      lds_barrier();  // tile `buf` is complete: computational levels k .. ktop-1
+      const int ktop = min(k + T, kend + 1);
+      int jlo = 0;  // first output level whose lowest row, max(kidx - 2, 0), lies in or above this tile
+      if (k > 0) {
+        int lo = 0, hi = jhi;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if ((int)kidx[mid] >= k + 2)
+            hi = mid;
+          else
+            lo = mid + 1;
+        }
+        jlo = lo;
+      }
+      const d2* cur = tile2 + (size_t)buf * (2 * T * nb2);
+      // written by the previous round: dn of level ktop, up of levels ktop and ktop+1 (dn is never needed above ktop: its
+      // rows are ka-1 and ka-2, and ka <= ktop+1 for every level emitted here)
+      const d2* hal = halo2 + (size_t)((g + 1) & 1) * (3 * nb2);
+      auto row = [&](int q, int r, int p) -> d2 {  // array q (0 = dn, 1 = up), computational level r, band pair p
+        return r < ktop ? cur[(q * T + (r - k)) * nb2 + p] : hal[(q + (r - ktop)) * nb2 + p];
+      };
+      const int n = (jhi - jlo) * nb2;  // band pairs to emit: output levels jlo .. jhi-1 are one contiguous run per array
+      d2* o0 = reinterpret_cast<d2*>(cfg.out[0]) + ((long long)c * nzo + jlo) * nb2;
+      d2* o1 = reinterpret_cast<d2*>(cfg.out[1]) + ((long long)c * nzo + jlo) * nb2;
+      d2* o2 = reinterpret_cast<d2*>(cfg.out[2]) + ((long long)c * nzo + jlo) * nb2;
+      d2* o3 = reinterpret_cast<d2*>(cfg.out[3]) + ((long long)c * nzo + jlo) * nb2;
+      {
+        const int dt = nst / nb2, dp = nst - dt * nb2;
+        int t = sid / nb2, p = sid - (sid / nb2) * nb2;
+        for (int idx = sid; idx < n; idx += nst) {
+          const int j = jlo + t;
+          const int ka = (int)kidx[j];
+          const double w = wgt[j];
+          const d2 da = row(0, ka - 1, p), db = row(0, max(ka - 2, 0), p);            // SWd[ka], SWd[ka-1]  (:310 clamp)
+          const d2 ua = row(1, min(ka, Mg - 1), p), ub = row(1, ka - 1, p);           // SWu[ka], SWu[ka-1]  (:335 clamp)
+          const d2 dn = da + (db - da) * w;  // :360
+          const d2 up = ua + (ub - ua) * w;  // :361
+          const d2 idr = bandc2[p] * ekl[j];  // :354-355
+          o0[idx] = idr;
+          o1[idx] = dn;
+          o2[idx] = up;
+          o3[idx] = idr * invmu + 2 * up + 2 * dn;  // :412
+          p += dp;
+          t += dt;
+          if (p >= nb2) {
+            p -= nb2;
+            ++t;
+          }
+        }
+      }
+      // halo for the next round: the two lowest levels of this tile
+      if (ktop - k >= 2) {
+        d2* hw = halo2 + (size_t)(g & 1) * (3 * nb2);
+        for (int idx = sid; idx < 3 * nb2; idx += nst)  // dn row 0 | up rows 0, 1 (adjacent in the tile)
+          hw[idx] = idx < nb2 ? cur[idx] : cur[(T - 1) * nb2 + idx];
+      }
+      jhi = jlo;
+      buf ^= 1;
+      ++g;
+    }
+  }
+}
+
+template <int M, int T, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_zqpa_pipe(SolveArgs a, PipeCfg cfg) {
+  extern __shared__ double lds[];
+  {
+    const double* src = a.ws + (long long)blockIdx.x * a.reclen;
+    for (int i = threadIdx.x; i < a.reclen; i += blockDim.x) lds[i] = src[i];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x >= cfg.ncomp) {
+    zqpa_pipe_store<M, T>(a, cfg, lds);
+    return;
+  }
+  tri_pipe_compute<TriZqPa, double, M, T, 0, 2>(a, cfg, lds);
+}
+
+// returns CRT_ERR_UNSUPPORTED when the shape does not fit (caller falls back to the two-kernel path)
+template <int M, int T>
+int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
+  if (a.nb % 2 || a.nb < 64) return CRT_ERR_UNSUPPORTED;
+  for (int i = 0; i < 4; ++i)
+    if (reinterpret_cast<uintptr_t>(a.o[i]) & 15) return CRT_ERR_UNSUPPORTED;
+  const int Mg = zqpa_M(a.nz);
+  const int ncomp = ((a.nb + 63) / 64) * 64;
+  // store waves (nsw <= 0: automatic).  Measured (tools/ab_zqpa.py), two-kernel path -> fused with 2 / 3 / 4 / 5 store waves:
+  //   1e4 x 300 x 60: 3.16 ms -> 1.51 / 1.34 / 1.67 / 1.60;  6e3 x 300 x 100 (one workgroup per CU): 3.16 -> 1.88 / 1.70 / 1.61 / 1.56;
+  //   3e4 x 128 x 60: 3.47 -> 1.56 / 2.26 / 2.26 / 2.15
+  const size_t lds_doubles = (size_t)((a.reclen + 1) & ~1) + ((a.nb + 1) & ~1) + 2 * (size_t)(Mg / M + 1) * ncomp + 4 * (size_t)T * a.nb + 6 * (size_t)a.nb;
+  if (nsw <= 0) nsw = ncomp <= 128 ? 2 : (lds_doubles * sizeof(double) > MAX_WG_LDS / 2 ? 5 : 3);
+  if (ncomp + 64 * nsw > 1024) nsw = (1024 - ncomp) / 64;
+  if (nsw < 1) return CRT_ERR_UNSUPPORTED;
+  const int nthr = ncomp + 64 * nsw;
+  SolveArgs g = a;  // computational-grid solve: nz := Mg; the outputs go through PipeCfg
+  g.nz = Mg;
+  for (int i = 0; i < 7; ++i) g.o[i] = nullptr;
+  PipeCfg cfg;
+  cfg.ncomp = ncomp;
+  cfg.nck = Mg / M + 1;  // K = Mg + 1 rows
+  cfg.off_bc = (a.reclen + 1) & ~1;
+  cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
+  cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
+  cfg.off_halo = cfg.off_tile + 2 * 2 * T * a.nb;
+  cfg.nz_out = a.nz;
+  for (int i = 0; i < 4; ++i) cfg.out[i] = a.o[i];
+  const size_t sh = ((size_t)cfg.off_halo + 2 * 3 * a.nb) * sizeof(double);
+  if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
+  auto go = [&](auto kern) {
+    if (sh > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+      return (int)CRT_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, g, cfg);
+    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+  };
+  return nthr <= 512 ? go(k_zqpa_pipe<M, T, 512>) : go(k_zqpa_pipe<M, T, 1024>);
+}
+
 }  // namespace
 
 int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s) {
   if (a.f32) return CRT_ERR_UNSUPPORTED;  // the computational-grid scratch is fp64; f32 storage not wired for zq_pa yet
+  if (g_tri_tune[2] != 1) {  // fused interpolation first (tune key 10 = 1: the two-kernel path with workspace scratch)
+    const int nsw = g_tri_tune[3];
+    int st = launch_zqpa_fused<16, 4>(a, s, nsw);
+    if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<12, 4>(a, s, nsw);
+    if (st != CRT_ERR_UNSUPPORTED) return st;
+  }
   const int M = zqpa_M(a.nz);
   SolveArgs g = a;  // computational-grid solve: nz := M, outputs := scratch
   g.nz = M;

@@ -437,3 +437,37 @@ def test_common_tau_functions_vs_reference():
         assert common.K_df_fn(K, 4.0, method="9sky") == pytest.approx(float(g[f"{name}__K_d_9sky"]), rel=1e-13)
     with pytest.raises(ValueError):
         common.tau_df_fn(lambda p: 0.5 / np.cos(p), lai, method="simpson")
+
+
+@pytest.mark.parametrize("shape", [(23, 300, 60), (130, 64, 13), (5, 600, 33), (4, 128, 150), (3, 300, 250), (6, 300, 3), (5, 300, 2), (7, 96, 101)])
+@pytest.mark.parametrize("uniform", [True, False])
+def test_zq_pa_fused_interpolation_equals_two_kernel_path(shape, uniform):
+    """zq_pa in one kernel (the store waves interpolate from the computational grid to the caller's levels; no workspace scratch) must be
+    BITWISE the two-kernel path (grid solve into scratch + k_zqpa_interp; crt_hip_tune(10, 1) selects it): same expressions, and the
+    rounds must hand every output level exactly the computational rows it needs (nz below, at and above the 100-layer grid)."""
+    import torch
+
+    from crt1d_amd import _lib, batched, synth
+
+    lib = _lib.load()
+    d = synth.make_columns(*shape, seed=5, uniform_dlai=uniform)
+    cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
+    try:
+        lib.crt_hip_tune(10, 1)
+        ref = batched.Plan("zq_pa", cols, bands)
+        ref()
+        torch.cuda.synchronize()
+    finally:
+        lib.crt_hip_tune(10, 0)
+    for nsw in (0, 1, 4):
+        try:
+            lib.crt_hip_tune(11, nsw)
+            p = batched.Plan("zq_pa", cols, bands)
+            for v in p.out.values():
+                v.fill_(float("nan"))
+            p()
+            torch.cuda.synchronize()
+        finally:
+            lib.crt_hip_tune(11, 0)
+        for k in ref.out:
+            assert torch.equal(p.out[k], ref.out[k]), (k, nsw)
