@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libcrt1d_hip.so")
 
 # enum crt_scheme
 SCHEME_IDS = {"2s": 0, "4s": 1, "n79": 2, "zq": 3, "bl": 4, "g77": 5, "bf": 6, "zq_pa": 7}
-F32_SCHEMES = ("2s", "4s", "n79", "zq", "bl", "g77", "bf")  # zq_pa: f64 only so far
+F32_SCHEMES = ("2s", "4s", "n79", "zq", "bl", "g77", "bf", "zq_pa")
 TAU_D_METHODS = {"quad": 0, "9sky": 1}
 NQ_TAU, NQ_G4, NQ_9SKY = 96, 32, 9
 NQ = NQ_TAU + NQ_G4 + NQ_9SKY
@@ -88,6 +88,7 @@ EXPORTS = [
     "crt_hip_bl_f32",
     "crt_hip_g77_f32",
     "crt_hip_bf_f32",
+    "crt_hip_zq_pa_f32",
     "crt_hip_absorb_bandsum_f64",
     "crt_hip_integrated_f64",
     "crt_hip_absorb_f64",

@@ -362,6 +362,7 @@ CRT_ENTRY32(crt_hip_zq_f32, CRT_SCHEME_ZQ)
 CRT_ENTRY32(crt_hip_bl_f32, CRT_SCHEME_BL)
 CRT_ENTRY32(crt_hip_g77_f32, CRT_SCHEME_G77)
 CRT_ENTRY32(crt_hip_bf_f32, CRT_SCHEME_BF)
+CRT_ENTRY32(crt_hip_zq_pa_f32, CRT_SCHEME_ZQ_PA)
 #undef CRT_ENTRY32
 
 int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, const double* I_dr, const double* I_df_d,

@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256) void k_zqpa_interp(InterpArgs a) {
 // (k_zqpa_interp's index arithmetic), i.e. it is complete once the tile holding row max(ka-2, 0) has arrived; the one or two
 // rows above the tile that it may also need are the two lowest rows of the previous tile, kept in a small halo buffer.
 // Same expressions as k_zqpa_interp -> bitwise the same profiles, 5.8 GB less HBM traffic of 11.5 GB at 1e4 x 300 x 60.
-template <int M, int T>
+template <typename TIO, int M, int T>
 __device__ __forceinline__ void zqpa_pipe_store(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
+  typedef TIO vt __attribute__((ext_vector_type(2)));
   static_assert(T >= 2, "the halo holds the two lowest rows of a tile");
   const int nb2 = a.nb >> 1, Mg = a.nz, nzo = cfg.nz_out;
   const int c = blockIdx.x;
@@ -104,10 +105,11 @@ __device__ __forceinline__ void zqpa_pipe_store(const SolveArgs& a, const PipeCf
         return r < ktop ? cur[(q * T + (r - k)) * nb2 + p] : hal[(q + (r - ktop)) * nb2 + p];
       };
       const int n = (jhi - jlo) * nb2;  // band pairs to emit: output levels jlo .. jhi-1 are one contiguous run per array
-      d2* o0 = reinterpret_cast<d2*>(cfg.out[0]) + ((long long)c * nzo + jlo) * nb2;
-      d2* o1 = reinterpret_cast<d2*>(cfg.out[1]) + ((long long)c * nzo + jlo) * nb2;
-      d2* o2 = reinterpret_cast<d2*>(cfg.out[2]) + ((long long)c * nzo + jlo) * nb2;
-      d2* o3 = reinterpret_cast<d2*>(cfg.out[3]) + ((long long)c * nzo + jlo) * nb2;
+      vt* o0 = reinterpret_cast<vt*>(cfg.out[0]) + ((long long)c * nzo + jlo) * nb2;
+      vt* o1 = reinterpret_cast<vt*>(cfg.out[1]) + ((long long)c * nzo + jlo) * nb2;
+      vt* o2 = reinterpret_cast<vt*>(cfg.out[2]) + ((long long)c * nzo + jlo) * nb2;
+      vt* o3 = reinterpret_cast<vt*>(cfg.out[3]) + ((long long)c * nzo + jlo) * nb2;
+      auto cvt = [](d2 x) -> vt { vt r; r.x = (TIO)x.x; r.y = (TIO)x.y; return r; };
       {
         const int dt = nst / nb2, dp = nst - dt * nb2;
         int t = sid / nb2, p = sid - (sid / nb2) * nb2;
@@ -120,10 +122,10 @@ __device__ __forceinline__ void zqpa_pipe_store(const SolveArgs& a, const PipeCf
           const d2 dn = da + (db - da) * w;  // :360
           const d2 up = ua + (ub - ua) * w;  // :361
           const d2 idr = bandc2[p] * ekl[j];  // :354-355
-          o0[idx] = idr;
-          o1[idx] = dn;
-          o2[idx] = up;
-          o3[idx] = idr * invmu + 2 * up + 2 * dn;  // :412
+          o0[idx] = cvt(idr);
+          o1[idx] = cvt(dn);
+          o2[idx] = cvt(up);
+          o3[idx] = cvt(idr * invmu + 2 * up + 2 * dn);  // :412
           p += dp;
           t += dt;
           if (p >= nb2) {
@@ -145,7 +147,7 @@ __device__ __forceinline__ void zqpa_pipe_store(const SolveArgs& a, const PipeCf
   }
 }
 
-template <int M, int T, int MAXT>
+template <typename TIO, int M, int T, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_zqpa_pipe(SolveArgs a, PipeCfg cfg) {
   extern __shared__ double lds[];
   {
@@ -154,18 +156,18 @@ __global__ __launch_bounds__(MAXT) void k_zqpa_pipe(SolveArgs a, PipeCfg cfg) {
   }
   __syncthreads();
   if ((int)threadIdx.x >= cfg.ncomp) {
-    zqpa_pipe_store<M, T>(a, cfg, lds);
+    zqpa_pipe_store<TIO, M, T>(a, cfg, lds);
     return;
   }
-  tri_pipe_compute<TriZqPa, double, M, T, 0, 2>(a, cfg, lds);
+  tri_pipe_compute<TriZqPa, TIO, M, T, 0, 2>(a, cfg, lds);
 }
 
 // returns CRT_ERR_UNSUPPORTED when the shape does not fit (caller falls back to the two-kernel path)
-template <int M, int T>
+template <typename TIO, int M, int T>
 int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
   if (a.nb % 2 || a.nb < 64) return CRT_ERR_UNSUPPORTED;
   for (int i = 0; i < 4; ++i)
-    if (reinterpret_cast<uintptr_t>(a.o[i]) & 15) return CRT_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) return CRT_ERR_UNSUPPORTED;
   const int Mg = zqpa_M(a.nz);
   const int ncomp = ((a.nb + 63) / 64) * 64;
   // store waves (nsw <= 0: automatic).  Measured (tools/ab_zqpa.py), two-kernel path -> fused with 2 / 3 / 4 / 5 store waves:
@@ -197,17 +199,22 @@ int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, g, cfg);
     return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
   };
-  return nthr <= 512 ? go(k_zqpa_pipe<M, T, 512>) : go(k_zqpa_pipe<M, T, 1024>);
+  return nthr <= 512 ? go(k_zqpa_pipe<TIO, M, T, 512>) : go(k_zqpa_pipe<TIO, M, T, 1024>);
 }
 
 }  // namespace
 
 int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s) {
-  if (a.f32) return CRT_ERR_UNSUPPORTED;  // the computational-grid scratch is fp64; f32 storage not wired for zq_pa yet
-  if (g_tri_tune[2] != 1) {  // fused interpolation first (tune key 10 = 1: the two-kernel path with workspace scratch)
+  if (g_tri_tune[2] != 1 || a.f32) {  // fused interpolation first (tune key 10 = 1: the two-kernel path with workspace scratch)
     const int nsw = g_tri_tune[3];
-    int st = launch_zqpa_fused<16, 4>(a, s, nsw);
-    if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<12, 4>(a, s, nsw);
+    int st;
+    if (a.f32) {
+      st = launch_zqpa_fused<float, 16, 4>(a, s, nsw);
+      if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<float, 12, 4>(a, s, nsw);
+      return st;  // f32 storage exists in the fused kernel only (the two-kernel path keeps its computational-grid scratch in fp64)
+    }
+    st = launch_zqpa_fused<double, 16, 4>(a, s, nsw);
+    if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<double, 12, 4>(a, s, nsw);
     if (st != CRT_ERR_UNSUPPORTED) return st;
   }
   const int M = zqpa_M(a.nz);

@@ -185,7 +185,7 @@ def test_plan_flags_and_strided_outputs():
         batched.Plan("2s", cols, bands, workspace=torch.empty(16, dtype=torch.uint8, device="cuda"))
 
 
-@pytest.mark.parametrize("scheme", ["2s", "4s", "bl", "g77", "bf", "n79", "zq"])
+@pytest.mark.parametrize("scheme", ["2s", "4s", "bl", "g77", "bf", "n79", "zq", "zq_pa"])
 @pytest.mark.parametrize("shape", [(21, 300, 60), (5, 107, 61), (9, 64, 13), (40, 6, 20), (3, 130, 100), (2, 40, 400), (1, 1500, 30)])
 def test_f32_storage_variant(scheme, shape):
     """crt_hip_*_f32: float spectra in, float profiles out, fp64 arithmetic.  Feeding the SAME (float-representable)
@@ -200,6 +200,10 @@ def test_f32_storage_variant(scheme, shape):
     cols = batched.Columns.from_host(d)
     b32 = batched.Bands.from_host({k: (d[k].astype(np.float32) if k in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r") else d[k]) for k in d})
     assert b32.dtype == torch.float32
+    if scheme == "zq_pa" and (nb % 2 or nb < 64 or nb > 832):  # f32 zq_pa exists in the single-kernel form only
+        with pytest.raises(RuntimeError, match="not supported"):
+            batched.solve(scheme, cols, b32)
+        return
     b64 = batched.Bands(*[None if t is None else t.double() for t in (b32.I_dr0, b32.I_df0, b32.leaf_r, b32.leaf_t, b32.soil_r)])
     s32 = batched.solve(scheme, cols, b32)
     s64 = batched.solve(scheme, cols, b64)
