@@ -2,25 +2,37 @@
 """
 bench.py -- the hot path of BASELINE.json measured on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--scheme 2s] [--ncol 10000] [--nb 300] [--nz 60]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scheme 2s] [--ncol 10000] [--nb 300] [--nz 60] [--partition column|band]
 
 Workload (N = 1): BASELINE.json configs[1] -- ``solve_2s`` batched over 1e4 synthetic profiles x 300 bands x
 60 levels, fp64, inputs resident in HBM before the timed region.  One *step* = one pass of the hot path over
 the batch = column-precompute kernel K0 + the solve kernel, through the C ABI (``crt_hip_2s_f64``).
-N > 1 (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``): the (column x band) grid is
-sharded by column blocks, every rank solves its own ``--ncol`` columns (weak scaling), no data-path collective
-(independent units); only the timing is reduced (max over ranks).
+
+N > 1: ``python bench.py --gpus N`` starts N rank processes ITSELF (children of a parent that never touches the GPU, rendezvous
+on 127.0.0.1) unless it already runs under ``torch.distributed.run`` (WORLD_SIZE set), one rank per GPU over RCCL.
+* ``--partition column`` (default): the (column x band) grid is sharded by column blocks, every rank solves its own ``--ncol``
+  columns (weak scaling), no data-path collective (independent units); the timing is max-reduced.  After
+  the timed region the ranks all-reduce a vector of ones (``rccl.ranks_seen``) and time the all-reduce of a config-4-sized
+  message (``rccl.allreduce_ms``) -- reported, never part of ``value``.
+* ``--partition band`` (BASELINE.json configs[3]; defaults zq, 1e5 columns, 100 levels): every rank solves ITS bands of ALL
+  columns (K0 replicated), forms partial band sums (``crt_hip_absorb_bandsum_f64``) and the packed sums of every column tile are
+  all-reduced over RCCL while the next tile is being solved (``crt1d_amd.dist.BandShardPlan``).  Strong scaling: the total
+  work is fixed, ``value`` = ncol x nb x steps / time.
 
 Prints ONE JSON line on rank 0.  ``roofline``: the dominant kernel (the solve kernel, launched alone with
-CRT_FLAG_SKIP_PRECOMPUTE between two HIP events on its own stream) against the 8 TB/s HBM3E peak;
-algorithmic bytes per solve as SURVEY section 8(d) / BASELINE.md section 3.  ``cpu_baseline``: the NumPy oracle
-(a port of the reference algorithm; the reference itself is pure Python and cannot travel to the GPU box)
-timed on this box's host cores on a bounded sample of the same workload, rank 0, N = 1 only.
+CRT_FLAG_SKIP_PRECOMPUTE between two HIP events on its own stream) against the 8 TB/s HBM3E peak; algorithmic bytes per solve
+as SURVEY section 8(d) / BASELINE.md section 3.  The timed block of K steps is repeated ``--repeats`` times: ``ms_per_step`` /
+``value`` come from the MEDIAN block, min and max are reported beside it.  ``cpu_baseline``: the NumPy oracle (a port of the
+reference algorithm; the reference itself is pure Python and cannot travel to the GPU box) timed on this box's host cores on a
+bounded sample of the same workload, rank 0, N = 1 only; ``cpu_baseline.reference_shaped`` is a per-band Python loop with the
+reference's structure and the here-measured ratio to the real reference (oracle/ref_ratio.json).  ``pcie_inclusive``: the same
+step with H2D of the inputs and D2H of the profiles (never ``value``).
 """
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,9 +48,6 @@ N_IO = {  # scheme: (n_in, n_full, n_mid)
     "2s": (5, 4, 0), "4s": (5, 4, 0), "bl": (4, 4, 0), "g77": (5, 7, 0), "bf": (5, 7, 0), "n79": (5, 4, 2), "zq": (5, 7, 0),
     "zq_pa": (5, 4, 0),
 }
-# dominant kernel per scheme as rocprofv3 names it (template arguments abbreviated)
-KERNEL_NAMES = {"2s": "k_pipe<Sch2s>", "4s": "k_pipe<Sch4s>", "bl": "k_pipe<SchBl>", "g77": "k_tile<SchG77<false>>",
-                "bf": "k_tile<SchG77<true>>", "n79": "k_tri_pipe<TriN79>", "zq": "k_tri_pipe<TriZq>", "zq_pa": "k_zqpa_pipe (grid solve + interpolation in one kernel)"}
 
 
 def bytes_per_solve(scheme, nz, s=8):
@@ -46,6 +55,8 @@ def bytes_per_solve(scheme, nz, s=8):
     return s * (n_in + n_full * nz + n_mid * (nz - 1))
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): oracle = test infrastructure, used here only as the thing being timed beside the GPU
 def _cpu_worker(args):
     """One host process: time the oracle on its own chunk (spawned, never touches the GPU)."""
     scheme, nb, nz, seed, budget_s = args
@@ -73,9 +84,9 @@ def _cpu_worker(args):
 def cpu_baseline_all_cores(scheme, nb, nz, nproc, budget_s=8.0):
     """Aggregate oracle rate of `nproc` independent host processes (one per core).
     Plain subprocesses of this script (`--cpu-worker`), each with a hard timeout: they import NumPy only, never the GPU."""
-    import subprocess
-
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker"]
     procs = [subprocess.Popen(cmd + [scheme, str(nb), str(nz), str(1000 + i), str(budget_s)], stdout=subprocess.PIPE,
                               stderr=subprocess.DEVNULL, text=True, env=env) for i in range(nproc)]
@@ -87,15 +98,59 @@ def cpu_baseline_all_cores(scheme, nb, nz, nproc, budget_s=8.0):
             solves, secs = out.split()[-2:]
             total += float(solves) / float(secs)
         except Exception:
-            p.kill()
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
             raise
     return total
 
 
-def cpu_baseline(scheme, nb, nz, budget_s=15.0):
-    """Oracle (NumPy port of the reference algorithm) on the host: solves/s on 1 core, bounded sample."""
-    import numpy as np
+def reference_shaped_baseline(scheme, nb, nz, budget_s=6.0):
+    """The reference's structure on this box's host: one column per call and, for 2s, a genuine per-band Python loop
+    (oracle/ref_shaped.py).  Returns the rate and what turns it into a reference-equivalent (oracle/ref_ratio.json: the same
+    stand-in timed beside the REAL reference in the build container)."""
+    from crt1d_amd import synth
+    from oracle import crt_oracle as O
 
+    ratios = {}
+    try:
+        with open(os.path.join(ROOT, "oracle", "ref_ratio.json")) as f:
+            ratios = json.load(f)
+    except Exception:
+        pass
+    d = synth.make_columns(20, nb, nz, seed=98)
+    oc = O.Columns(d["psi"], d["lai"], mla=d["mla"], g_kind=d["g_kind"], g_param=d["g_param"])
+    out = {}
+    if scheme == "2s":
+        from oracle import ref_shaped
+
+        solves, secs = ref_shaped.time_2s_loop(d, O.mu_bar(oc), oc.K_b(), budget_s=budget_s)
+        rate, kind, key = solves / secs, "per-band Python loop, one column per call (oracle/ref_shaped.py: structure of _solve_2s.py:54-156)", "ratio_ref_shaped"
+    else:
+        kw = dict(I_dr0=d["I_dr0"], I_df0=d["I_df0"], leaf_r=d["leaf_r"], leaf_t=d["leaf_t"], soil_r=d["soil_r"])
+        if scheme == "bl":
+            kw.pop("soil_r")
+        fn = O.SOLVERS[scheme]
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < budget_s:
+            c = n % 20
+            o1 = O.Columns(d["psi"][c:c + 1], d["lai"][c:c + 1], mla=d["mla"][c:c + 1], g_kind=d["g_kind"][c:c + 1], g_param=d["g_param"][c:c + 1])
+            fn(o1, **{k: v[c:c + 1] for k, v in kw.items()})
+            n += 1
+        rate, kind, key = n * nb / (time.perf_counter() - t0), "oracle called one column at a time (vectorised over bands)", "ratio_oracle_percol"
+    out = {"value": rate, "unit": "solves/s", "cores": 1, "what": kind}
+    e = ratios.get(scheme, {})
+    if key in e and (nb, nz) == (ratios.get("_meta", {}).get("nb"), ratios.get("_meta", {}).get("nz")):
+        out["ratio_to_reference"] = e[key]  # stand-in rate / real reference rate, build container, same nb x nz
+        out["reference_equivalent"] = rate / e[key]
+        out["reference_measured_in_build_container"] = e["reference"]
+        out["ratio_source"] = "oracle/ref_ratio.json (oracle/measure_ref_ratio.py: real crt1d.solvers beside the stand-in, 1 core)"
+    return out
+
+
+def cpu_baseline(scheme, nb, nz, budget_s=15.0):
+    """Oracle (NumPy port of the reference algorithm) on the host: solves/s on 1 core and on the box's cores, bounded sample."""
     from crt1d_amd import synth
     from oracle import crt_oracle as O
 
@@ -113,17 +168,8 @@ def cpu_baseline(scheme, nb, nz, budget_s=15.0):
         fn(oc, **kw)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 400:
+        if el > budget_s * 0.5 or n >= 400:
             break
-    # reference-shaped variant: one column per call (the reference has no batching), a few columns only
-    t1 = time.perf_counter()
-    ncs = 0
-    for c in range(min(chunk, 20)):
-        o1 = O.Columns(d["psi"][c:c + 1], d["lai"][c:c + 1], mla=d["mla"][c:c + 1], g_kind=d["g_kind"][c:c + 1],
-                       g_param=d["g_param"][c:c + 1])
-        fn(o1, **{k: v[c:c + 1] for k, v in kw.items()})
-        ncs += 1
-    per_col = (time.perf_counter() - t1) / ncs
     one_core = n * chunk * nb / el
     nproc = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
     all_cores = None
@@ -133,12 +179,15 @@ def cpu_baseline(scheme, nb, nz, budget_s=15.0):
         except Exception as e:  # never lose the bench line over the baseline
             print(f"all-core CPU baseline failed: {e!r}", file=sys.stderr)
     sample = (f"oracle.solve_{scheme} (NumPy port of the reference algorithm, vectorised over {chunk}-column chunks), {nb} bands x {nz} "
-              f"levels: 1 core {one_core:.3g} solves/s ({n * chunk} columns in {el:.1f} s); one-column-per-call (reference-shaped) "
-              f"{nb / per_col:.3g} solves/s on 1 core; host has {os.cpu_count()} logical cores")
+              f"levels: 1 core {one_core:.3g} solves/s ({n * chunk} columns in {el:.1f} s); host has {os.cpu_count()} logical cores")
+    out = {"value": one_core, "unit": "solves/s", "cores": 1, "kind": "port", "sample": sample}
     if all_cores is not None:
-        return {"value": all_cores, "unit": "solves/s", "cores": nproc, "kind": "port",
-                "sample": sample + f"; value = {nproc} independent processes, 8 s each"}
-    return {"value": one_core, "unit": "solves/s", "cores": 1, "kind": "port", "sample": sample}
+        out.update(value=all_cores, cores=nproc, sample=sample + f"; value = {nproc} independent processes, 8 s each")
+    try:
+        out["reference_shaped"] = reference_shaped_baseline(scheme, nb, nz, budget_s=min(6.0, budget_s * 0.4))
+    except Exception as e:
+        print(f"reference-shaped CPU baseline failed: {e!r}", file=sys.stderr)
+    return out
 
 
 def load_pmc_traffic(scheme, ncol, nb, nz):
@@ -156,43 +205,143 @@ def load_pmc_traffic(scheme, ncol, nb, nz):
         return None
 
 
-def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":  # helper process of cpu_baseline_all_cores
-        scheme, nb, nz, seed, budget = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
-        solves, secs = _cpu_worker((scheme, nb, nz, seed, budget))
-        print(solves, secs)
-        return
+# ------------------------------------------------------------------------------------------------------------------
+# self-launch: N rank processes as CHILDREN of this (GPU-free) process
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv, timeout_s):
+    """Start `n` rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as
+    torch.distributed.run would set them) and wait.  Rank 0 inherits stdout (it prints the JSON line); the exit code is the
+    first non-zero one.  Nothing here imports torch or touches the GPU, and nothing is exec'ed."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + timeout_s
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+            if rc != 0 or time.time() > deadline:
+                if rc == 0:
+                    rc = 124
+                    print(f"bench.py: ranks still running after {timeout_s:.0f} s; stopping them", file=sys.stderr)
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:  # exactly the processes started here
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--scheme", default="2s", choices=sorted(N_IO))
-    ap.add_argument("--placement", default="auto", choices=["auto", "none"], help="output-buffer placement search at plan creation")
-    ap.add_argument("--ncol", type=int, default=10000, help="columns PER GPU")
+    ap.add_argument("--steps", type=int, default=None, help="steps per timed block (default 100; 10 with --partition band)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps first (default 20; 3 with --partition band)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median block is reported")
+    ap.add_argument("--scheme", default=None, choices=sorted(N_IO))
+    ap.add_argument("--partition", default="column", choices=["column", "band"],
+                    help="'column': column blocks per rank, no data-path collective (weak scaling, the headline); 'band': band blocks "
+                         "per rank + RCCL all-reduce of the spectral integrals (BASELINE configs[3], strong scaling)")
+    ap.add_argument("--column-tiles", type=int, default=4, help="--partition band: column tiles per step (all-reduce of tile i overlaps tile i+1)")
+    ap.add_argument("--placement", default="auto", choices=["auto", "none"], help="output arrays from the class-interleaving set allocator "
+                    "(crt_hip_buffer_alloc_set) or from torch.empty")
+    ap.add_argument("--ncol", type=int, default=None, help="columns PER GPU (column partition; default 10000) or in TOTAL (band partition; default 100000)")
     ap.add_argument("--nb", type=int, default=300)
-    ap.add_argument("--nz", type=int, default=60)
+    ap.add_argument("--nz", type=int, default=None)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
                     help="storage type of spectra/profiles; arithmetic is fp64 either way (f32 = config 5 variant, not the headline)")
     ap.add_argument("--variant", default="profiles", choices=["profiles", "integrated"],
                     help="'integrated': fused solve + absorption + band integrals (crt_hip_integrated_f64), no profiles written; "
                          "a separately reported variant with its own byte count, NOT the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the H2D + step + D2H measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; 'gloo' + --share-device rehearses the N>1 code path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--launch-check", action="store_true", help="N>1: rendezvous + all-reduce of ones only (no GPU work; CPU test of the launcher)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0)
     ap.add_argument("--cpu-budget", type=float, default=15.0)
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
+    band = a.partition == "band"
+    if a.scheme is None:
+        a.scheme = "zq" if band else "2s"
+    if a.ncol is None:
+        a.ncol = 100000 if band else 10000
+    if a.nz is None:
+        a.nz = 100 if band else 60
+    if a.steps is None:
+        a.steps = 10 if band else 100
+    if a.warmup is None:
+        a.warmup = 3 if band else 20
+    return a
 
-    import torch
-    import torch.distributed as dist
+
+def kernel_name(lib):
+    try:
+        return lib.crt_hip_last_kernel().decode()
+    except Exception:
+        return None
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":  # helper process of cpu_baseline_all_cores
+        scheme, nb, nz, seed, budget = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
+        solves, secs = _cpu_worker((scheme, nb, nz, seed, budget))
+        print(solves, secs)
+        return 0
+    a = parse_args(sys.argv[1:])
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's command shape is `python bench.py --gpus N ...`: become the launcher (before anything touches the GPU)
+        return launch_ranks(a.gpus, sys.argv[1:], a.launch_timeout)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit(f"--gpus {a.gpus} needs: python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...")
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
+    if a.launch_check:  # launcher / rendezvous test without a GPU
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.ones(1, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": int(t.item()), "master": os.environ.get("MASTER_ADDR")}))
+        return 0
+
     if a.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -206,25 +355,10 @@ def main():
 
     from crt1d_amd import _lib, batched, synth
 
+    lib = _lib.load()
     scheme, ncol, nb, nz = a.scheme, a.ncol, a.nb, a.nz
-    # column shard of this rank: its own seed -> distinct columns of one global grid
-    d = synth.make_columns(ncol, nb, nz, seed=1234 + rank)
-    cols = batched.Columns.from_host(d, dev)
-    if a.dtype == "f32":
-        import numpy as np
-
-        d = {k: (v.astype(np.float32) if k in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r") else v) for k, v in d.items()}
-    bands = batched.Bands.from_host(d, dev)
-    NG = 3  # PAR, NIR, solar
-    if a.variant == "integrated":
-        from crt1d_amd import spectra
-
-        plan = batched.IntegratedPlan(scheme, cols, bands, torch.as_tensor(spectra.band_weights(d["wle"])).to(dev))
-    else:
-        # output buffers are allocated once, before the timed region; placement="auto" lets the plan pick where they live
-        # (the same kernel runs ~15 % faster or slower depending on where the driver put them)
-        plan = batched.Plan(scheme, cols, bands, placement=a.placement)
     stream = torch.cuda.current_stream(dev)
+    NG = 3  # PAR, NIR, solar
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -232,73 +366,246 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        plan()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        plan()
-    barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    solves_per_step = ncol * nb * world
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    def timed_blocks(step, finish=None):
+        """--warmup untimed steps, then --repeats blocks of EXACTLY --steps steps, each bracketed by barrier + synchronize on both
+        sides; per block the max over ranks."""
+        for _ in range(a.warmup):
+            step()
+        if finish:
+            finish()
+        blocks = []
+        for _ in range(max(1, a.repeats)):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            if finish:
+                finish()
+            barrier()
+            blocks.append(max_over_ranks(time.perf_counter() - t0))
+        return blocks
+
+    f32 = a.dtype == "f32"
+    band = a.partition == "band"
+    extra = {}
+    if band:
+        # ---------------------------------------------------------------- band partition: BASELINE configs[3]
+        from crt1d_amd import dist as cdist
+        from crt1d_amd import spectra
+
+        if a.variant != "profiles" or f32:
+            raise SystemExit("--partition band runs the fp64 profile path (solve + epilogue + all-reduce)")
+        d = synth.make_columns(ncol, nb, nz, seed=1234)  # the SAME columns on every rank: K0 is replicated, the bands are sharded
+        cols = batched.Columns.from_host(d, dev)
+        bands = batched.Bands.from_host(d, dev)
+        bw = torch.as_tensor(spectra.band_weights(d["wle"])).to(dev)
+        plan = cdist.BandShardPlan(scheme, cols, bands, bw, column_tiles=a.column_tiles, share_profiles=True, placement=a.placement)
+        del bands
+        nb_local = plan.band_range[1] - plan.band_range[0]
+        res_holder = {}
+
+        def step():
+            plan()
+            res_holder["r"] = plan.wait()
+
+        blocks = timed_blocks(step)
+        solves_per_step = ncol * nb  # the whole problem, whatever N is
+        # compute only (no collective), and the collective alone on the same messages
+        def compute_only():
+            plan(reduce=False)
+
+        compute_blocks = timed_blocks(compute_only)
+        coll_ms, ranks_seen = None, 1
+        if world > 1:
+            ones = torch.ones(1, dtype=torch.float64, device=red_dev)
+            dist.all_reduce(ones)
+            ranks_seen = int(ones.item())
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                for tile in plan.tiles:
+                    dist.all_reduce(tile.flat)
+            barrier()
+            coll_ms = max_over_ranks((time.perf_counter() - t0) / 5 * 1e3)
+        kname = kernel_name(lib)
+        knames = [kname]
+        if world > 1:
+            knames = [None] * world
+            dist.all_gather_object(knames, (rank, plan.band_range, kname))
+        ref = res_holder["r"]["reflectance"]
+        extra = {
+            "partition": "band blocks per rank (K0 replicated) + packed fp64 all-reduce per column tile",
+            "bands_this_rank": nb_local,
+            "column_tiles": plan.ntile,
+            "collective": {
+                "backend": "RCCL (nccl)" if a.backend == "nccl" else "gloo (rehearsal)", "ranks_seen": ranks_seen,
+                "message_bytes_per_step": plan.message_bytes, "messages_per_step": plan.ntile,
+                "collective_ms_alone": coll_ms,
+                "compute_only_ms_per_step": sorted(compute_blocks)[len(compute_blocks) // 2] / a.steps * 1e3,
+                "semantics": "sum over bands of w * X (crt1d/diagnostics.py:81); reflectance = reflected / incoming after the reduce (:510-511)",
+            },
+            "kernels_per_rank": knames,
+            "check": {"mean_solar_reflectance": float(ref[:, 2].mean()), "finite": bool(torch.isfinite(ref).all())},
+        }
+        main_plan = plan.tiles[0].kernel_plan
+        ncol_kernel = plan.tiles[0].chi - plan.tiles[0].clo
+        nb_kernel = nb_local
+    else:
+        # ---------------------------------------------------------------- column partition: the headline
+        d = synth.make_columns(ncol, nb, nz, seed=1234 + rank)  # this rank's column block: its own seed -> distinct columns of one grid
+        cols = batched.Columns.from_host(d, dev)
+        if f32:
+            import numpy as np
+
+            d = {k: (v.astype(np.float32) if k in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r") else v) for k, v in d.items()}
+        bands = batched.Bands.from_host(d, dev)
+        if a.variant == "integrated":
+            from crt1d_amd import spectra
+
+            main_plan = batched.IntegratedPlan(scheme, cols, bands, torch.as_tensor(spectra.band_weights(d["wle"])).to(dev))
+        else:
+            # output buffers are allocated once, before the timed region (placement="auto": crt_hip_buffer_alloc_set, DESIGN.md 3.1)
+            main_plan = batched.Plan(scheme, cols, bands, placement=a.placement)
+        blocks = timed_blocks(lambda: main_plan())
+        solves_per_step = ncol * nb * world
+        ncol_kernel, nb_kernel = ncol, nb
+        if world > 1:
+            # RCCL evidence for the scaling runs (outside the timed region, never part of `value`): did the collective see N ranks,
+            # and what does the all-reduce of one config-4 column tile's packed sums (2.5e4 x (99 x 9 + 12) doubles = 181 MB) cost here
+            ones = torch.ones(1, dtype=torch.float64, device=red_dev)
+            dist.all_reduce(ones)
+            msg = torch.zeros(25000 * (99 * 9 + 12), dtype=torch.float64, device=red_dev)
+            dist.all_reduce(msg)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                dist.all_reduce(msg)
+            barrier()
+            ar_ms = max_over_ranks((time.perf_counter() - t0) / 5 * 1e3)
+            knames = [None] * world
+            dist.all_gather_object(knames, (rank, kernel_name(lib)))
+            extra["rccl"] = {"backend": "RCCL (nccl)" if a.backend == "nccl" else "gloo (rehearsal)", "ranks_seen": int(ones.item()),
+                             "allreduce_ms": ar_ms, "allreduce_bytes": msg.numel() * 8,
+                             "busbw_GBs": 2 * (world - 1) / world * msg.numel() * 8 / (ar_ms * 1e-3) / 1e9, "kernels_per_rank": knames,
+                             "note": "measured after the timed region; the column partition has no data-path collective"}
+            del msg
+
+    blocks_sorted = sorted(blocks)
+    el = blocks_sorted[len(blocks_sorted) // 2]  # median block
     value = solves_per_step * a.steps / el
 
     # ---- dominant kernel alone, HIP events on the stream it is launched on ----
-    reps = max(20, a.steps)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for _ in range(3):
-        plan(flags=_lib.FLAG_SKIP_PRECOMPUTE)
-    torch.cuda.synchronize(dev)
-    for e0, e1 in evs:
+    roof = None
+    if main_plan is not None:
+        reps = max(20, min(a.steps, 100))
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for _ in range(3):
+            main_plan(flags=_lib.FLAG_SKIP_PRECOMPUTE)
+        torch.cuda.synchronize(dev)
+        for e0, e1 in evs:
+            e0.record(stream)
+            main_plan(stream, flags=_lib.FLAG_SKIP_PRECOMPUTE)
+            e1.record(stream)
+        torch.cuda.synchronize(dev)
+        kname = kernel_name(lib)
+        kt = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        k_ms_avg = sum(kt) / len(kt)
+        k_ms_med = kt[len(kt) // 2]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        plan(stream, flags=_lib.FLAG_SKIP_PRECOMPUTE)
+        for _ in range(10):
+            main_plan(stream, flags=_lib.FLAG_PRECOMPUTE_ONLY)
         e1.record(stream)
-    torch.cuda.synchronize(dev)
-    kt = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
-    k_ms_avg = sum(kt) / len(kt)
-    k_ms_med = kt[len(kt) // 2]
-    # K0 alone
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(10):
-        plan(stream, flags=_lib.FLAG_PRECOMPUTE_ONLY)
-    e1.record(stream)
-    torch.cuda.synchronize(dev)
-    k0_ms = e0.elapsed_time(e1) / 10
-
-    bps = bytes_per_solve(scheme, nz, 4 if a.dtype == "f32" else 8)
-    if a.variant == "integrated":  # B = s n_in + s n_red (nz-1) / nb  (SURVEY 8(d)); n_red = 3 quantities x NG groups
-        bps = 8 * N_IO[scheme][0] + 8 * 3 * NG * (nz - 1) / nb
-    alg_bytes = bps * ncol * nb  # per launch, this GPU
-    achieved = alg_bytes / (k_ms_avg * 1e-3) / 1e9
-
-    # ---- measured HBM ceilings from the same run (streaming fill / copy of 4 GiB) ----
-    lib = _lib.load()
-    n = 1 << 29  # doubles = 4 GiB
-    buf = torch.empty(n, dtype=torch.float64, device=dev)
-    src = torch.empty(n, dtype=torch.float64, device=dev).fill_(1.0)
-
-    def timed(fn, nrep=5):
-        fn()
         torch.cuda.synchronize(dev)
-        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a0.record(stream)
-        for _ in range(nrep):
+        k0_ms = e0.elapsed_time(e1) / 10
+
+        bps = bytes_per_solve(scheme, nz, 4 if f32 else 8)
+        if a.variant == "integrated":  # B = s n_in + s n_red (nz-1) / nb  (SURVEY 8(d)); n_red = 3 quantities x NG groups
+            bps = 8 * N_IO[scheme][0] + 8 * 3 * NG * (nz - 1) / nb
+        alg_bytes = bps * ncol_kernel * nb_kernel  # per launch, this GPU
+        achieved = alg_bytes / (k_ms_avg * 1e-3) / 1e9
+
+        # ---- measured HBM ceilings from the same run (streaming fill / copy of 4 GiB) ----
+        n = 1 << 29  # doubles = 4 GiB
+        buf = torch.empty(n, dtype=torch.float64, device=dev)
+        src = torch.empty(n, dtype=torch.float64, device=dev).fill_(1.0)
+
+        def timed(fn, nrep=5):
             fn()
-        a1.record(stream)
-        torch.cuda.synchronize(dev)
-        return a0.elapsed_time(a1) / nrep * 1e-3
+            torch.cuda.synchronize(dev)
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record(stream)
+            for _ in range(nrep):
+                fn()
+            a1.record(stream)
+            torch.cuda.synchronize(dev)
+            return a0.elapsed_time(a1) / nrep * 1e-3
 
-    t_fill = timed(lambda: lib.crt_hip_probe_fill_f64(buf.data_ptr(), n, 0.5, stream.cuda_stream))
-    t_copy = timed(lambda: lib.crt_hip_probe_copy_f64(buf.data_ptr(), src.data_ptr(), n, stream.cuda_stream))
-    fill_gbs = 8 * n / t_fill / 1e9
-    copy_gbs = 2 * 8 * n / t_copy / 1e9
-    del buf, src
+        t_fill = timed(lambda: lib.crt_hip_probe_fill_f64(buf.data_ptr(), n, 0.5, stream.cuda_stream))
+        t_copy = timed(lambda: lib.crt_hip_probe_copy_f64(buf.data_ptr(), src.data_ptr(), n, stream.cuda_stream))
+        fill_gbs = 8 * n / t_fill / 1e9
+        copy_gbs = 2 * 8 * n / t_copy / 1e9
+        del buf, src
+        roof = {
+            "bound": "hbm",
+            "kernel": kname,
+            "note": None if a.variant == "profiles" else "integrated variant is compute-bound: the HBM fraction is informational only",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": load_pmc_traffic(scheme, ncol_kernel, nb_kernel, nz) if (not f32 and a.variant == "profiles") else None,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "bytes_per_solve": bps,
+            "launch_shape": [ncol_kernel, nb_kernel, nz],
+            "kernel_ms_avg": k_ms_avg,
+            "kernel_ms_median": k_ms_med,
+            "kernel_ms_min": kt[0],
+            "kernel_ms_max": kt[-1],
+            "k0_ms": k0_ms,
+            "measured_fill_GBs": fill_gbs,
+            "measured_copy_GBs": copy_gbs,
+            "frac_of_measured_fill": achieved / fill_gbs,
+        }
 
+    # ---- PCIe-inclusive step (N = 1, column partition): H2D of the per-band inputs + K0 + solve + D2H of every profile ----
+    pcie = None
+    if world == 1 and not band and a.variant == "profiles" and not a.no_pcie and rank == 0:
+        try:
+            out_bytes = sum(v.numel() * v.element_size() for v in main_plan.out.values())
+            if out_bytes <= (24 << 30):
+                host_in = {k: getattr(bands, k).cpu().pin_memory() for k in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r") if getattr(bands, k) is not None}
+                host_out = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in main_plan.out.items()}
+                in_bytes = sum(v.numel() * v.element_size() for v in host_in.values())
+
+                def pcie_step():
+                    for k, v in host_in.items():
+                        getattr(bands, k).copy_(v, non_blocking=True)
+                    main_plan()
+                    for k, v in main_plan.out.items():
+                        host_out[k].copy_(v, non_blocking=True)
+
+                pcie_step()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    pcie_step()
+                torch.cuda.synchronize(dev)
+                pt = (time.perf_counter() - t0) / 3
+                pcie = {"value": ncol * nb / pt, "unit": "solves/s", "ms_per_step": pt * 1e3, "h2d_bytes": in_bytes, "d2h_bytes": out_bytes,
+                        "GBs": (in_bytes + out_bytes) / pt / 1e9, "note": "pinned host buffers; transfer-bound; never `value`"}
+                del host_in, host_out
+        except Exception as e:
+            print(f"pcie-inclusive measurement failed: {e!r}", file=sys.stderr)
+
+    per_step = [b / a.steps * 1e3 for b in blocks]
     out = {
         "metric": ("(column x band) solves/sec at 60 layers" if nz == 60 else f"(column x band) solves/sec at {nz} layers")
                   + (" [integrated outputs only]" if a.variant == "integrated" else ""),
@@ -308,38 +615,27 @@ def main():
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": el / a.steps * 1e3,
+        "ms_per_step_blocks": {"repeats": len(blocks), "median": el / a.steps * 1e3, "min": min(per_step), "max": max(per_step), "all": per_step},
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if band else "weak",
         "vs_baseline": None,
-        "dtype": "f64" if a.dtype == "f64" else "f64 arithmetic, f32 storage",
+        "dtype": "f64" if not f32 else "f64 arithmetic, f32 storage",
         "data": "synthetic",
         "config": {
-            "workload": f"solve_{scheme} batched: {ncol} synthetic profiles x {nb} bands x {nz} levels per GPU, fp64 "
-                        f"(BASELINE.json configs[1] shape)" if (scheme, ncol, nb, nz) == ("2s", 10000, 300, 60) else
-                        f"solve_{scheme} batched: {ncol} synthetic profiles x {nb} bands x {nz} levels per GPU, fp64",
-            "scheme": scheme, "ncol_per_gpu": ncol, "nb": nb, "nz": nz, "partition": "column blocks, no collective",
-            "step": "K0 column precompute + solve kernel via crt_hip_%s_f64" % scheme,
-            "output_placement": getattr(plan, "placement_report", None),
-        },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": KERNEL_NAMES[scheme] if a.variant == "profiles" else ("k_int" if scheme in ("2s", "4s", "bl", "g77", "bf") else "k_tri_int"),
-            "note": None if a.variant == "profiles" else "integrated variant is compute-bound: the HBM fraction is informational only",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": load_pmc_traffic(scheme, ncol, nb, nz) if (a.dtype == "f64" and a.variant == "profiles") else None,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "bytes_per_solve": bps,
-            "kernel_ms_avg": k_ms_avg,
-            "kernel_ms_median": k_ms_med,
-            "k0_ms": k0_ms,
-            "measured_fill_GBs": fill_gbs,
-            "measured_copy_GBs": copy_gbs,
-            "frac_of_measured_fill": achieved / fill_gbs,
+            "workload": (f"solve_{scheme} batched: {ncol} synthetic profiles x {nb} bands x {nz} levels " + ("in total, band-sharded" if band else "per GPU")
+                         + ", fp64" + (" (BASELINE.json configs[1] shape)" if (scheme, ncol, nb, nz, band) == ("2s", 10000, 300, 60, False) else "")
+                         + (" (BASELINE.json configs[3] shape)" if (scheme, ncol, nb, nz, band) == ("zq", 100000, 300, 100, True) else "")),
+            "scheme": scheme, ("ncol_total" if band else "ncol_per_gpu"): ncol, "nb": nb, "nz": nz,
+            "partition": extra.pop("partition", "column blocks, no collective"),
+            "step": ("K0 column precompute + solve kernel via crt_hip_%s_f64" % scheme) + (" + crt_hip_absorb_bandsum_f64 + all-reduce, per column tile" if band else ""),
+            "output_placement": getattr(main_plan, "placement_report", None) if a.placement == "auto" else "torch.empty (--placement none)",
         },
     }
+    out["config"].update(extra)
+    if roof is not None:
+        out["roofline"] = roof
+    if pcie is not None:
+        out["pcie_inclusive"] = pcie
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scheme, nb, nz, a.cpu_budget)
     if world > 1:
@@ -347,7 +643,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

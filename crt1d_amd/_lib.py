@@ -57,8 +57,11 @@ class CrtBands(ctypes.Structure):
     ]
 
 
+NTUNE = 12
+
+
 class CrtOptions(ctypes.Structure):
-    _fields_ = [("mu_s", ctypes.c_double), ("tau_d_method", ctypes.c_int32), ("flags", ctypes.c_int32)]
+    _fields_ = [("mu_s", ctypes.c_double), ("tau_d_method", ctypes.c_int32), ("flags", ctypes.c_int32), ("tune", ctypes.c_int32 * NTUNE)]
 
 
 class CrtOutputs(ctypes.Structure):
@@ -95,9 +98,13 @@ EXPORTS = [
     "crt_hip_tau_d_f64",
     "crt_hip_smear_tuv_f64",
     "crt_hip_lai_beta_f64",
+    "crt_hip_buffer_alloc_set",
     "crt_hip_buffer_alloc",
     "crt_hip_buffer_free",
-    "crt_hip_tune",
+    "crt_hip_buffer_trim",
+    "crt_hip_buffer_describe",
+    "crt_hip_buffer_stats",
+    "crt_hip_last_kernel",
     "crt_hip_probe_fill_f64",
     "crt_hip_probe_copy_f64",
 ]
@@ -174,13 +181,21 @@ def load():
     lib.crt_hip_buffer_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
     lib.crt_hip_buffer_free.restype = ctypes.c_int
     lib.crt_hip_buffer_free.argtypes = [ctypes.c_void_p]
-    lib.crt_hip_tune.restype = None
-    lib.crt_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.crt_hip_buffer_alloc_set.restype = ctypes.c_int
+    lib.crt_hip_buffer_alloc_set.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_void_p)]
+    lib.crt_hip_buffer_trim.restype = ctypes.c_int
+    lib.crt_hip_buffer_trim.argtypes = []
+    lib.crt_hip_buffer_describe.restype = ctypes.c_int
+    lib.crt_hip_buffer_describe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    lib.crt_hip_buffer_stats.restype = ctypes.c_int
+    lib.crt_hip_buffer_stats.argtypes = [ctypes.POINTER(ctypes.c_int64)]
+    lib.crt_hip_last_kernel.restype = ctypes.c_char_p
+    lib.crt_hip_last_kernel.argtypes = []
     lib.crt_hip_probe_fill_f64.restype = ctypes.c_int
     lib.crt_hip_probe_fill_f64.argtypes = [_vp, ctypes.c_size_t, ctypes.c_double, _vp]
     lib.crt_hip_probe_copy_f64.restype = ctypes.c_int
     lib.crt_hip_probe_copy_f64.argtypes = [_vp, _vp, ctypes.c_size_t, _vp]
-    if lib.crt_hip_abi_version() != 1:
+    if lib.crt_hip_abi_version() != 2:
         raise HipLibraryMissing(f"{LIB_PATH}: ABI version mismatch, rebuild")
     _lib = lib
     return lib

@@ -56,6 +56,22 @@ def _fio(t, name):
     return t.contiguous()
 
 
+def _check_profile(t, name, shape, device, dtype=torch.float64):
+    """A caller-supplied profile / output array: the C ABI receives a bare pointer, so everything the kernels assume about it
+    (dtype, shape, device, contiguity) is checked here."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_cuda or t.device != device:
+        raise ValueError(f"{name} must live on {device} (got {t.device})")
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
 @dataclass
 class Columns:
     """Device-resident per-column canopy geometry (what one reference ``Model`` holds)."""
@@ -114,15 +130,25 @@ class Columns:
             raise AssertionError("psi must be in [0, pi/2)")
         if not bool(((self.g_kind >= 0) & (self.g_kind <= 6)).all()):
             raise ValueError("invalid leaf-angle kind")
-        if bool((self.g_kind == 6).any()) and (self.g_table is None or self.g_at_psi is None):
-            raise ValueError("columns with g_kind = G_TABLE need g_table and g_at_psi")
+        self.check_tables()
         return self
+
+    def check_tables(self):
+        """Columns of kind G_TABLE dereference ``g_table`` / ``g_at_psi`` on the device: when either is missing make sure no
+        column asks for it (one device->host sync, and only in the case where a table is missing)."""
+        if getattr(self, "_tables_ok", False):
+            return
+        if (self.g_table is None or self.g_at_psi is None) and bool((self.g_kind == 6).any()):
+            raise ValueError("columns with g_kind = G_TABLE need g_table and g_at_psi")
+        self._tables_ok = True  # checked once per object; slices inherit the result (no sync inside a tiled, overlapped loop)
 
     def slice(self, lo, hi):
         """Columns [lo, hi) as a view (used by the column-sharded multi-GPU path)."""
         g = lambda t: None if t is None else t[lo:hi]  # noqa: E731
-        return Columns(self.psi[lo:hi], self.lai[lo:hi], self.g_kind[lo:hi], self.g_param[lo:hi], g(self.mla),
-                       g(self.g_at_psi), g(self.g_table))
+        c = Columns(self.psi[lo:hi], self.lai[lo:hi], self.g_kind[lo:hi], self.g_param[lo:hi], g(self.mla),
+                    g(self.g_at_psi), g(self.g_table))
+        c._tables_ok = getattr(self, "_tables_ok", False)
+        return c
 
     def c_struct(self):
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
@@ -203,29 +229,45 @@ class Bands:
         return cls(t("I_dr0"), t("I_df0"), t("leaf_r"), t("leaf_t"), t("soil_r"))
 
 
+def _check_band_device(bands, device):
+    for name in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r"):
+        v = getattr(bands, name)
+        if v is not None and v.device != device:
+            raise ValueError(f"{name} lives on {v.device} but the columns on {device}")
+
+
+def _check_workspace(workspace, need, device):
+    if workspace is None:
+        return torch.empty(need, dtype=torch.uint8, device=device)
+    if not isinstance(workspace, torch.Tensor) or not workspace.is_cuda or workspace.device != device:
+        raise ValueError(f"workspace must be a tensor on {device}")
+    if not workspace.is_contiguous() or workspace.numel() * workspace.element_size() < need:
+        raise ValueError(f"workspace too small or not contiguous (need {need} bytes)")
+    return workspace
+
+
 def workspace_bytes(scheme, ncol, nz, nb=1):
     """Device workspace a solve needs; ``nb`` matters for zq_pa only (its computational-grid fluxes live there)."""
     return int(_lib.load().crt_hip_workspace_bytes_nb(_lib.SCHEME_IDS[scheme], ncol, nz, nb))
 
 
 class _DeviceBuffer:
-    """Owner of one ``crt_hip_buffer_alloc`` allocation; exposes it to torch through ``__cuda_array_interface__`` (the
-    tensor made from it keeps this object, and with it the memory, alive)."""
+    """Owner of one buffer of a ``crt_hip_buffer_alloc_set`` allocation; exposes it to torch through
+    ``__cuda_array_interface__`` (the tensor made from it keeps this object, and with it the memory, alive)."""
 
-    def __init__(self, shape, dtype, device):
+    def __init__(self, ptr, shape, dtype, device):
         self._lib = _lib.load()
-        self._ptr = ctypes.c_void_p()
+        self._ptr = ctypes.c_void_p(ptr)
         self._dev = torch.device(device)
-        itemsize = torch.empty((), dtype=dtype).element_size()
-        n = 1
-        for s in shape:
-            n *= int(s)
-        with torch.cuda.device(self._dev):
-            _lib.check(self._lib.crt_hip_buffer_alloc(max(n, 1) * itemsize, ctypes.byref(self._ptr)), "crt_hip_buffer_alloc")
         self.__cuda_array_interface__ = {
             "shape": tuple(int(s) for s in shape), "typestr": {torch.float64: "<f8", torch.float32: "<f4"}[dtype],
-            "data": (self._ptr.value, False), "version": 2, "strides": None,
+            "data": (ptr, False), "version": 2, "strides": None,
         }
+
+    def classes(self):
+        buf = ctypes.create_string_buffer(4096)
+        _lib.check(self._lib.crt_hip_buffer_describe(self._ptr, buf, len(buf)), "crt_hip_buffer_describe")
+        return buf.value.decode()
 
     def __del__(self):
         if getattr(self, "_ptr", None) is not None and self._ptr.value:
@@ -237,24 +279,76 @@ class _DeviceBuffer:
             self._ptr = None
 
 
-def device_buffer(shape, dtype=torch.float64, device="cuda"):
-    """A tensor backed by 1 GB physical chunks (``crt_hip_buffer_alloc``, include/crt1d_hip.h); falls back to nothing: raises
-    if the virtual-memory API is unavailable."""
+_OWNERS = "_crt_owner"  # attribute under which a tensor made by device_buffers() carries its _DeviceBuffer
+
+
+def device_buffers(shapes, dtype=torch.float64, device="cuda"):
+    """Tensors for ONE output set (arrays a kernel writes in step), placed by ``crt_hip_buffer_alloc_set``: 512 MB physical chunks
+    whose memory classes are interleaved across the arrays (include/crt1d_hip.h; csrc/buffers.hip).  Raises if the HIP
+    virtual-memory API is unavailable -- callers that can live with any placement catch the error and use ``torch.empty``."""
+    lib = _lib.load()
     dev = torch.device(device)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
-    return torch.as_tensor(_DeviceBuffer(shape, dtype, dev), device=dev)
+    itemsize = torch.empty((), dtype=dtype).element_size()
+    n = len(shapes)
+    sizes = []
+    for shape in shapes:
+        k = itemsize
+        for s in shape:
+            k *= int(s)
+        sizes.append(max(k, itemsize))
+    c_sizes = (ctypes.c_size_t * n)(*sizes)
+    c_ptrs = (ctypes.c_void_p * n)()
+    with torch.cuda.device(dev):
+        _lib.check(lib.crt_hip_buffer_alloc_set(n, c_sizes, c_ptrs), "crt_hip_buffer_alloc_set")
+    out = []
+    for ptr, shape in zip(c_ptrs, shapes):
+        owner = _DeviceBuffer(ptr, shape, dtype, dev)
+        t = torch.as_tensor(owner, device=dev)
+        setattr(t, _OWNERS, owner)
+        out.append(t)
+    return out
 
 
-def alloc_outputs(scheme, ncol, nz, nb, device, dtype=torch.float64, chunked=False):
-    """Output arrays of one scheme; ``chunked=True`` backs arrays of at least 64 MB with 1 GB physical chunks."""
-    out = {}
+def device_buffer(shape, dtype=torch.float64, device="cuda"):
+    """One tensor from ``crt_hip_buffer_alloc`` (a set of one)."""
+    return device_buffers([shape], dtype, device)[0]
+
+
+def buffer_classes(t):
+    """Memory-class letters of the chunks behind a tensor made by :func:`device_buffers` (``None`` for any other tensor)."""
+    owner = getattr(t, _OWNERS, None)
+    return None if owner is None else owner.classes()
+
+
+def buffer_stats(device=None):
+    """``crt_hip_buffer_stats`` of the current (or given) device as a dict."""
+    lib = _lib.load()
+    a = (ctypes.c_int64 * 6)()
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        _lib.check(lib.crt_hip_buffer_stats(a), "crt_hip_buffer_stats")
+    return dict(zip(("chunks_created", "chunks_released", "probes", "probe_us", "free_chunks", "classes_seen"), [int(v) for v in a]))
+
+
+PLACED_MIN_BYTES = 1 << 30  # below this the whole output set lives in the 256 MB Infinity Cache / a few chunks: plain torch memory
+
+
+def alloc_outputs(scheme, ncol, nz, nb, device, dtype=torch.float64, placed=False):
+    """Output arrays of one scheme.  ``placed=True``: through :func:`device_buffers` (class-interleaved 512 MB chunks) when the
+    set is at least ``PLACED_MIN_BYTES``; otherwise (or if the virtual-memory API fails) plain ``torch.empty``."""
+    shapes = {}
     for k in OUT_KEYS[scheme]:
         n = nz - 1 if k in _MID_KEYS.get(scheme, ()) else nz
-        shape = (ncol, n, nb)
-        big = ncol * n * nb * (8 if dtype == torch.float64 else 4) >= (64 << 20)
-        out[k] = device_buffer(shape, dtype, device) if (chunked and big) else torch.empty(shape, dtype=dtype, device=device)
-    return out
+        shapes[k] = (ncol, n, nb)
+    item = 8 if dtype == torch.float64 else 4
+    total = sum(s[0] * s[1] * s[2] * item for s in shapes.values())
+    if placed and total >= PLACED_MIN_BYTES:
+        try:
+            return dict(zip(shapes, device_buffers(list(shapes.values()), dtype, device)))
+        except RuntimeError:
+            pass  # placement is a performance feature: any device memory is correct
+    return {k: torch.empty(s, dtype=dtype, device=device) for k, s in shapes.items()}
 
 
 class Plan:
@@ -262,7 +356,10 @@ class Plan:
     on the current stream with no allocation and no host synchronisation (bench / steady-state use)."""
 
     def __init__(self, scheme, cols: Columns, bands: Bands, *, mu_s=0.501, tau_d_method="quad", out=None, workspace=None,
-                 placement="none"):
+                 placement="auto", tune=None):
+        """``placement``: ``"auto"`` allocates output sets of 1 GB and more through the class-interleaving allocator
+        (``crt_hip_buffer_alloc_set``: deterministic ~7 TB/s store mode); ``"none"`` uses ``torch.empty``
+        (the store rate then depends on where the driver happens to put the arrays).  Ignored when ``out`` is given."""
         if scheme not in _lib.SCHEME_IDS:
             raise ValueError(f"unknown scheme {scheme!r}; valid: {', '.join(SCHEMES)}")
         if tau_d_method not in _lib.TAU_D_METHODS:
@@ -275,31 +372,44 @@ class Plan:
             raise ValueError("solve_2s needs `mla`")
         if scheme != "bl" and bands.soil_r is None:
             raise ValueError(f"solve_{scheme} needs `soil_r`")
-        self.out = alloc_outputs(scheme, ncol, nz, nb, cols.device, bands.dtype) if out is None else out
+        cols.check_tables()
+        _check_band_device(bands, cols.device)
+        if placement not in ("auto", "none"):
+            raise ValueError("placement must be 'auto' or 'none'")
+        placed = placement == "auto" and os.environ.get("CRT1D_PLACEMENT", "auto") != "none"
+        self.out = alloc_outputs(scheme, ncol, nz, nb, cols.device, bands.dtype, placed=placed) if out is None else out
         for k in OUT_KEYS[scheme]:
-            v = self.out[k]
-            if v.dtype != bands.dtype or not v.is_cuda or not v.is_contiguous():
-                raise TypeError(f"output {k!r} must be a contiguous CUDA tensor of dtype {bands.dtype}")
+            if k not in self.out:
+                raise ValueError(f"`out` lacks {k!r}")
+            rows = nz - 1 if k in _MID_KEYS.get(scheme, ()) else nz
+            _check_profile(self.out[k], f"output {k!r}", (ncol, rows, nb), cols.device, bands.dtype)
         need = workspace_bytes(scheme, ncol, nz, nb)
-        if workspace is None:
-            workspace = torch.empty(need, dtype=torch.uint8, device=cols.device)
-        elif workspace.numel() * workspace.element_size() < need:
-            raise ValueError("workspace too small")
+        workspace = _check_workspace(workspace, need, cols.device)
         self.workspace = workspace
         self._c = cols.c_struct()
         self._b = bands.c_struct(ncol)
         self._o = _lib.CrtOptions(float(mu_s), _lib.TAU_D_METHODS[tau_d_method], 0)
+        self.set_tune(tune or {})
         if bands.dtype == torch.float32 and scheme not in _lib.F32_SCHEMES:
             raise TypeError(f"scheme {scheme!r} has no f32 storage variant yet")
         self._entry = f"crt_hip_{scheme}_{'f32' if bands.dtype == torch.float32 else 'f64'}"
         self._fn = getattr(self.lib, self._entry)
         self._wsb = workspace.numel() * workspace.element_size()
         self._point_at(self.out)
-        self.placement_report = None
-        if placement == "auto" and out is None and os.environ.get("CRT1D_PLACEMENT", "auto") != "none":
-            self._choose_placement()
-        elif placement not in ("auto", "none"):
-            raise ValueError("placement must be 'auto' or 'none'")
+        # where the output arrays live: memory-class letters per 512 MB chunk for arrays from the set allocator (None = torch memory)
+        cls = {k: buffer_classes(v) for k, v in self.out.items()}
+        self.placement_report = {"allocator": "crt_hip_buffer_alloc_set", "classes": cls} if any(cls.values()) else None
+
+    def set_tune(self, tune):
+        """Measurement aid: per-plan overrides of the kernel-selection heuristics (``crt_options.tune``; keys in
+        csrc/crt_internal.hpp).  ``{}`` = automatic.  They travel with every call of this plan -- no process-global state."""
+        for k in range(_lib.NTUNE):
+            self._o.tune[k] = int(tune.get(k, 0))
+        return self
+
+    def last_kernel(self):
+        """Name / configuration of the solve kernel this thread's most recent call launched (``crt_hip_last_kernel``)."""
+        return self.lib.crt_hip_last_kernel().decode()
 
     def _point_at(self, out):
         self.out = out
@@ -307,154 +417,94 @@ class Plan:
         ptrs += [None] * (7 - len(ptrs))
         self._out = _lib.CrtOutputs(*ptrs)
 
-    def _time_ms(self, reps=3):
-        dev = self.cols.device
-        st = torch.cuda.current_stream(dev)
-        self(st, flags=_lib.FLAG_SKIP_PRECOMPUTE)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-        for _ in range(reps):
-            self(st, flags=_lib.FLAG_SKIP_PRECOMPUTE)
-        e1.record(st)
-        e1.synchronize()
-        return e0.elapsed_time(e1) / reps
-
-    def _choose_placement(self, nsets=4, nmix=12, seed=0x5EED):
-        """Pick WHERE the output arrays live.  The solve kernels are HBM-write-bound, and on MI355X the same kernel on the same
-        data runs in one of two modes depending on where the driver happened to place the output arrays in HBM: ~0.93 ms or
-        ~1.12 ms for 2s at 1e4 x 300 x 60, stable for the life of the allocation, nothing to do with their virtual addresses
-        (the slow mode shows twice the DRAM-credit stalls at the L2).  Since a Plan's buffers are
-        allocated once and reused, it is worth a fraction of a second: allocate a few candidate sets (each after a random-size
-        pad, which moves where the next allocation lands; every other one built from 1 GB physical chunks), time the solve on each,
-        try a few mixes of arrays across sets, keep the fastest and free the rest.  Skipped when the candidates would not fit comfortably in free memory."""
-        import random
-
-        dev = self.cols.device
-        total = sum(v.numel() * v.element_size() for v in self.out.values())
-        free, _ = torch.cuda.mem_get_info(dev)
-        if total < (256 << 20) or (nsets - 1) * total + (1 << 30) > free // 2:
-            return
-        with torch.cuda.device(dev):
-            rng = random.Random(seed)
-            self()  # K0 once: the timings below reuse the column records
-            sets, pads = [self.out], []
-            ncol, nz, nb = self.cols.ncol, self.cols.nz, self.bands.nb
-            for i in range(nsets - 1):
-                pads.append(torch.empty(rng.randrange(1, 150) << 21, dtype=torch.uint8, device=dev))
-                try:  # every other candidate is backed by 1 GB physical chunks (crt_hip_buffer_alloc): same two modes, a faster best case
-                    sets.append(alloc_outputs(self.scheme, ncol, nz, nb, dev, self.bands.dtype, chunked=(i % 2 == 0)))
-                except RuntimeError:
-                    sets.append(alloc_outputs(self.scheme, ncol, nz, nb, dev, self.bands.dtype))
-            # yardstick: the streaming-fill rate of this device, measured on one of the arrays; a candidate whose outputs are
-            # written faster than 1.02 x that rate ends the search early; otherwise all candidates (~10 timings, ~40 ms) are tried
-            big = max(self.out.values(), key=lambda v: v.numel() * v.element_size())
-            nfill = (big.numel() * big.element_size() // 16) * 2  # whole 16-B vectors, counted in doubles
-            st = torch.cuda.current_stream(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self.lib.crt_hip_probe_fill_f64(big.data_ptr(), nfill, 0.0, st.cuda_stream)
-            e0.record(st)
-            for _ in range(2):
-                self.lib.crt_hip_probe_fill_f64(big.data_ptr(), nfill, 0.0, st.cuda_stream)
-            e1.record(st)
-            e1.synchronize()
-            fill_bytes_per_ms = 2 * nfill * 8 / e0.elapsed_time(e1)
-            good_ms = total / (1.02 * fill_bytes_per_ms)  # (the best placements beat the grid-stride fill probe by a few per cent)
-            best, tbest, tworst, tried = None, float("inf"), 0.0, 0
-            trials = []  # (what, ms) in the order tried
-            keys = list(self.out)
-            cands = list(sets) + [None] * nmix  # None = a random mix of arrays across the sets
-            for ci, cand in enumerate(cands):
-                what = "torch" if ci == 0 else ("chunked" if ci % 2 == 1 else "torch+pad") if ci < nsets else "mix"
-                if cand is None:
-                    cand = {k: sets[rng.randrange(nsets)][k] for k in keys}
-                self._point_at(cand)
-                t = self._time_ms()
-                trials.append((what, round(t, 4)))
-                tried += 1
-                tworst = max(tworst, t)
-                if t < tbest:
-                    best, tbest = cand, t
-                if tbest <= good_ms:
-                    break
-            # nothing near the fill rate: every region tried so far is a slow one.  Jump further: behind a multi-GB pad, two fresh
-            # sets and a few mixes of their arrays land in other physical regions (bounded by a quarter of the free memory)
-            ok_ms = total / (0.93 * fill_bytes_per_ms)
-            for pad_gb in (8, 16, 32, 48):
-                if tbest <= ok_ms:
-                    break
-                free, _ = torch.cuda.mem_get_info(dev)
-                if (pad_gb << 30) + 2 * total > free // 4:
-                    break
-                pads.append(torch.empty(pad_gb << 30, dtype=torch.uint8, device=dev))
-                far = []
-                for chunked in (False, True):
-                    try:
-                        far.append(alloc_outputs(self.scheme, ncol, nz, nb, dev, self.bands.dtype, chunked=chunked))
-                    except RuntimeError:
-                        far.append(alloc_outputs(self.scheme, ncol, nz, nb, dev, self.bands.dtype))
-                sets.extend(far)
-                for j in range(6):
-                    cand = far[j] if j < 2 else {k: far[rng.randrange(2)][k] for k in keys}
-                    self._point_at(cand)
-                    t = self._time_ms()
-                    trials.append((f"+{pad_gb}GB {'torch' if j == 0 else 'chunked' if j == 1 else 'mix'}", round(t, 4)))
-                    tried += 1
-                    tworst = max(tworst, t)
-                    if t < tbest:
-                        best, tbest = cand, t
-                    if tbest <= ok_ms:
-                        break
-            self._point_at(best)
-            self.placement_report = {"candidates_timed": tried, "best_ms": tbest, "worst_ms": tworst, "fill_rate_ms": total / fill_bytes_per_ms,
-                                     "trials": trials}
-            del sets, pads
-            torch.cuda.empty_cache()
-
     def __call__(self, stream=None, *, flags=0):
         """Enqueue on ``stream`` (default: torch's current stream).  ``flags``: ``_lib.FLAG_SKIP_PRECOMPUTE`` reuses
         the column records already in the workspace (same geometry, new spectra); ``_lib.FLAG_PRECOMPUTE_ONLY``
         runs only the column precompute."""
-        s = torch.cuda.current_stream(self.cols.device) if stream is None else stream
+        dev = self.cols.device
+        s = torch.cuda.current_stream(dev) if stream is None else stream
         self._o.flags = int(flags)
-        st = self._fn(ctypes.byref(self._c), ctypes.byref(self._b), ctypes.byref(self._o), ctypes.byref(self._out),
-                      self.workspace.data_ptr(), self._wsb, s.cuda_stream)
+        with torch.cuda.device(dev):  # the launch goes to the CURRENT device: make it the one the buffers live on
+            st = self._fn(ctypes.byref(self._c), ctypes.byref(self._b), ctypes.byref(self._o), ctypes.byref(self._out),
+                          self.workspace.data_ptr(), self._wsb, s.cuda_stream)
         _lib.check(st, self._entry)
         return self.out
 
 
-def solve(scheme, cols: Columns, bands: Bands, *, mu_s=0.501, tau_d_method="quad", out=None, workspace=None):
+def solve(scheme, cols: Columns, bands: Bands, *, mu_s=0.501, tau_d_method="quad", out=None, workspace=None, placement="none"):
     """Run ``scheme`` over all (column, band) pairs; returns a dict of ``(ncol, nz, nb)`` CUDA tensors.
 
-    Asynchronous on the current stream, like any torch op.
+    Asynchronous on the current stream, like any torch op.  One-shot calls take their outputs from torch's caching allocator
+    (``placement="none"``); steady-state users build a :class:`Plan` once (``placement="auto"``).
     """
     with torch.cuda.device(cols.device):
-        return Plan(scheme, cols, bands, mu_s=mu_s, tau_d_method=tau_d_method, out=out, workspace=workspace)()
+        return Plan(scheme, cols, bands, mu_s=mu_s, tau_d_method=tau_d_method, out=out, workspace=workspace, placement=placement)()
 
 
-def absorb_bandsum(cols: Columns, bands: Bands, sol, band_w):
+def _check_epilogue_inputs(cols, bands, sol):
+    """The epilogue entry points are fp64 only (``crt_hip_absorb*_f64``): float32 profiles (the output of an f32 solve) read as
+    double would run past the end of the allocation."""
+    if bands.dtype != torch.float64:
+        raise TypeError("the epilogue kernels take float64 spectra and profiles (got float32 bands); upcast first")
+    _check_band_device(bands, cols.device)
+    bands.col_stride(cols.ncol)
+    cols.check_tables()
+    for k in ("I_dr", "I_df_d", "I_df_u"):
+        if k not in sol:
+            raise ValueError(f"`sol` lacks {k!r}")
+        _check_profile(sol[k], f"sol[{k!r}]", (cols.ncol, cols.nz, bands.nb), cols.device)
+
+
+BANDSUM_KEYS = ("aI", "aI_sl", "aI_sh", "totals")
+
+
+def bandsum_shapes(ncol, nz, ngroup):
+    """Shapes of the integrated outputs, in ``BANDSUM_KEYS`` order."""
+    return {"aI": (ncol, nz - 1, ngroup), "aI_sl": (ncol, nz - 1, ngroup), "aI_sh": (ncol, nz - 1, ngroup), "totals": (ncol, ngroup, 4)}
+
+
+class BandSumPlan:
+    """Pre-validated launch of the epilogue (``crt_hip_absorb_bandsum_f64``) on fixed buffers: ``plan()`` enqueues the kernel with
+    no allocation and no host synchronisation.  ``out`` may hold caller-owned output tensors (e.g. views into one packed
+    message buffer, :class:`crt1d_amd.dist.BandShardPlan`)."""
+
+    def __init__(self, cols: Columns, bands: Bands, sol, band_w, out=None):
+        self.lib = _lib.load()
+        band_w = _f64(band_w, "band_w")
+        if band_w.ndim == 1:
+            band_w = band_w[None, :]
+        ng = band_w.shape[0]
+        ncol, nz, dev = cols.ncol, cols.nz, cols.device
+        _check_epilogue_inputs(cols, bands, sol)
+        if band_w.shape[1] != bands.nb or not 1 <= ng <= 4 or band_w.device != dev:
+            raise ValueError(f"band_w must be (ngroup <= 4, nb = {bands.nb}) on {dev}")
+        shapes = bandsum_shapes(ncol, nz, ng)
+        if out is None:
+            out = {k: torch.empty(shapes[k], dtype=torch.float64, device=dev) for k in BANDSUM_KEYS}
+        else:
+            for k in BANDSUM_KEYS:
+                _check_profile(out[k], f"out[{k!r}]", shapes[k], dev)
+        self.cols, self.bands, self.sol, self.band_w, self.out, self.ng = cols, bands, sol, band_w, out, ng
+        self._c, self._b = cols.c_struct(), bands.c_struct(ncol)
+
+    def __call__(self, stream=None):
+        dev = self.cols.device
+        s = torch.cuda.current_stream(dev) if stream is None else stream
+        o, sol = self.out, self.sol
+        with torch.cuda.device(dev):
+            st = self.lib.crt_hip_absorb_bandsum_f64(
+                ctypes.byref(self._c), ctypes.byref(self._b), sol["I_dr"].data_ptr(), sol["I_df_d"].data_ptr(), sol["I_df_u"].data_ptr(),
+                self.band_w.data_ptr(), self.ng, o["aI"].data_ptr(), o["aI_sl"].data_ptr(), o["aI_sh"].data_ptr(), o["totals"].data_ptr(),
+                s.cuda_stream)
+        _lib.check(st, "crt_hip_absorb_bandsum_f64")
+        return self.out
+
+
+def absorb_bandsum(cols: Columns, bands: Bands, sol, band_w, out=None):
     """Layer absorption (``model.py:573-647``) reduced over bands with weights ``band_w (ngroup, nb)``
     (``diagnostics.py:39-108``).  Returns ``aI, aI_sl, aI_sh`` ``(ncol, nz-1, ngroup)`` and the
     energy-balance terms ``totals (ncol, ngroup, 4)`` = incoming, reflected, transmitted, soil-reflected."""
-    lib = _lib.load()
-    band_w = _f64(band_w, "band_w")
-    if band_w.ndim == 1:
-        band_w = band_w[None, :]
-    ng = band_w.shape[0]
-    ncol, nz = cols.ncol, cols.nz
-    dev = cols.device
-    aI = torch.empty((ncol, nz - 1, ng), dtype=torch.float64, device=dev)
-    aI_sl = torch.empty_like(aI)
-    aI_sh = torch.empty_like(aI)
-    totals = torch.empty((ncol, ng, 4), dtype=torch.float64, device=dev)
-    c, b = cols.c_struct(), bands.c_struct(ncol)
-    with torch.cuda.device(dev):
-        st = lib.crt_hip_absorb_bandsum_f64(
-            ctypes.byref(c), ctypes.byref(b), sol["I_dr"].data_ptr(), sol["I_df_d"].data_ptr(), sol["I_df_u"].data_ptr(),
-            band_w.data_ptr(), ng, aI.data_ptr(), aI_sl.data_ptr(), aI_sh.data_ptr(), totals.data_ptr(),
-            torch.cuda.current_stream(dev).cuda_stream,
-        )
-    _lib.check(st, "crt_hip_absorb_bandsum_f64")
-    return {"aI": aI, "aI_sl": aI_sl, "aI_sh": aI_sh, "totals": totals}
+    return dict(BandSumPlan(cols, bands, sol, band_w, out=out)())
 
 
 ABSORPTION_KEYS = ("aI", "aI_df", "aI_dr", "aI_sh", "aI_sl", "aI_df_sl", "aI_df_sh")  # model.py:637-647
@@ -466,6 +516,7 @@ def absorb(cols: Columns, bands: Bands, sol):
     lib = _lib.load()
     ncol, nz, nb = cols.ncol, cols.nz, bands.nb
     dev = cols.device
+    _check_epilogue_inputs(cols, bands, sol)
     out = {k: torch.empty((ncol, nz - 1, nb), dtype=torch.float64, device=dev) for k in ABSORPTION_KEYS}
     laim = torch.empty((ncol, nz - 1), dtype=torch.float64, device=dev)
     f_slm = torch.empty_like(laim)
@@ -485,7 +536,7 @@ class IntegratedPlan:
     """Fused solve + absorption + band integrals (``crt_hip_integrated_f64``): no profile ever reaches HBM.
     Outputs as :func:`absorb_bandsum`: ``aI, aI_sl, aI_sh (ncol, nz-1, ngroup)``, ``totals (ncol, ngroup, 4)``."""
 
-    def __init__(self, scheme, cols: Columns, bands: Bands, band_w, *, mu_s=0.501, tau_d_method="quad", workspace=None):
+    def __init__(self, scheme, cols: Columns, bands: Bands, band_w, *, mu_s=0.501, tau_d_method="quad", workspace=None, out=None):
         if scheme not in _lib.SCHEME_IDS or scheme == "zq_pa":
             raise ValueError(f"scheme {scheme!r} has no integrated kernel")
         if tau_d_method not in _lib.TAU_D_METHODS:
@@ -501,21 +552,36 @@ class IntegratedPlan:
             raise ValueError("band_w must be (ngroup <= 4, nb)")
         self.band_w = band_w
         ncol, nz, ng, dev = cols.ncol, cols.nz, band_w.shape[0], cols.device
-        self.out = {k: torch.empty((ncol, nz - 1, ng), dtype=torch.float64, device=dev) for k in ("aI", "aI_sl", "aI_sh")}
-        self.out["totals"] = torch.empty((ncol, ng, 4), dtype=torch.float64, device=dev)
+        shapes = bandsum_shapes(ncol, nz, ng)
+        if out is None:
+            out = {k: torch.empty(shapes[k], dtype=torch.float64, device=dev) for k in BANDSUM_KEYS}
+        else:
+            for k in BANDSUM_KEYS:
+                _check_profile(out[k], f"out[{k!r}]", shapes[k], dev)
+        self.out = out
+        cols.check_tables()
+        _check_band_device(bands, dev)
+        if band_w.device != dev:
+            raise ValueError(f"band_w lives on {band_w.device} but the columns on {dev}")
+        if scheme == "2s" and cols.mla is None:
+            raise ValueError("solve_2s needs `mla`")
+        if scheme != "bl" and bands.soil_r is None:
+            raise ValueError(f"solve_{scheme} needs `soil_r`")
         need = workspace_bytes(scheme, ncol, nz, bands.nb)
-        self.workspace = torch.empty(need, dtype=torch.uint8, device=dev) if workspace is None else workspace
+        self.workspace = _check_workspace(workspace, need, dev)
         self._c, self._b = cols.c_struct(), bands.c_struct(ncol)
         self._o = _lib.CrtOptions(float(mu_s), _lib.TAU_D_METHODS[tau_d_method], 0)
 
     def __call__(self, stream=None, *, flags=0):
-        s = torch.cuda.current_stream(self.cols.device) if stream is None else stream
+        dev = self.cols.device
+        s = torch.cuda.current_stream(dev) if stream is None else stream
         self._o.flags = int(flags)
         o = self.out
-        st = self.lib.crt_hip_integrated_f64(
-            _lib.SCHEME_IDS[self.scheme], ctypes.byref(self._c), ctypes.byref(self._b), ctypes.byref(self._o), self.band_w.data_ptr(),
-            self.band_w.shape[0], o["aI"].data_ptr(), o["aI_sl"].data_ptr(), o["aI_sh"].data_ptr(), o["totals"].data_ptr(),
-            self.workspace.data_ptr(), self.workspace.numel(), s.cuda_stream)
+        with torch.cuda.device(dev):
+            st = self.lib.crt_hip_integrated_f64(
+                _lib.SCHEME_IDS[self.scheme], ctypes.byref(self._c), ctypes.byref(self._b), ctypes.byref(self._o), self.band_w.data_ptr(),
+                self.band_w.shape[0], o["aI"].data_ptr(), o["aI_sl"].data_ptr(), o["aI_sh"].data_ptr(), o["totals"].data_ptr(),
+                self.workspace.data_ptr(), self.workspace.numel() * self.workspace.element_size(), s.cuda_stream)
         _lib.check(st, "crt_hip_integrated_f64")
         return self.out
 

@@ -259,10 +259,12 @@ static int solve_impl(int scheme, const crt_columns* cols, const crt_bands* band
   if (scheme == CRT_SCHEME_N79 && nz < 3) return CRT_ERR_SHAPE;  // td[1]/tb[1] of _solve_n79.py:85-92
   double mu_s = 0.501;
   int method = CRT_TAU_D_QUAD, flags = 0;
+  int tune[CRT_NTUNE] = {};
   if (opts) {
     mu_s = opts->mu_s;
     method = opts->tau_d_method;
     flags = opts->flags;
+    for (int i = 0; i < CRT_NTUNE; ++i) tune[i] = opts->tune[i];
   }
   if (scheme == CRT_SCHEME_4S && !(mu_s > 0.0 && mu_s < 1.0)) return CRT_ERR_BAD_ARG;
   if (method != CRT_TAU_D_QUAD && method != CRT_TAU_D_9SKY) return CRT_ERR_BAD_ARG;  // ValueError, common.py:78
@@ -311,6 +313,7 @@ static int solve_impl(int scheme, const crt_columns* cols, const crt_bands* band
   sa.o[6] = out->x2;
   sa.mu_s = mu_s;
   sa.f32 = f32;
+  for (int i = 0; i < CRT_NTUNE; ++i) sa.tune[i] = tune[i];
   if (integ) {
     if (scheme == CRT_SCHEME_ZQ_PA) return CRT_ERR_UNSUPPORTED;
     return tri ? launch_tridiag_int(scheme, sa, *integ, s) : launch_closed_int(scheme, sa, *integ, s);
@@ -449,12 +452,7 @@ int crt_hip_tau_d_f64(const double* kb_nodes, const double* L, int64_t n, int32_
   return crt::launch_tau_d(kb_nodes, L, (long long)n, method, out, static_cast<hipStream_t>(stream));
 }
 
-void crt_hip_tune(int key, int value) {
-  if (key >= 8)
-    tune_tridiag(key - 8, value);
-  else
-    tune_closed(key, value);
-}
+const char* crt_hip_last_kernel(void) { return last_kernel(); }
 
 int crt_hip_probe_fill_f64(double* dst, size_t n, double value, crt_stream_t stream) {
   if (!dst || n == 0 || (n & 1) || (reinterpret_cast<uintptr_t>(dst) & 15)) return CRT_ERR_BAD_ARG;

@@ -1,92 +1,420 @@
-// Device buffers for the output profiles, built with the HIP virtual-memory API from 1 GB physical allocations (plus one
-// tail allocation).  Measured with the solve kernels' store pattern (tools/vmm_bw.hip, profiles/r01/vmm_bw.log): arrays
-// backed by 1 GB physical chunks are written at 6.9 TB/s where 2-128 MB chunks or plain hipMalloc memory in the same
-// region give 6.7-6.8 TB/s.  Which physical region the driver hands out still decides between the fast and the slow mode
-// (DESIGN.md section 3.1); batched.Plan(placement="auto") times candidates of either kind.
+// Device buffers for the output profiles with a deterministic placement in HBM.
+//
+// Finding (round 2; tools/chunk_probe.hip, matrix_probe.hip, class_probe.hip, remap_probe.hip, hazard_probe.hip, logs under
+// profiles/r02/placement/): on MI355X every piece of physical memory belongs to one of (up to) three CLASSES.  The solve
+// kernels' store pattern -- one workgroup per column streaming T levels of every output array -- runs at ~5.5 TB/s when all the
+// memory being written at one time belongs to ONE class, whether that is one array, two or eight, and at 6.9-7.0 TB/s when it
+// is spread over two or three classes (50/50: 6.95, 25/75: 6.65, 1/7: 6.2).  The class is a property of the physical memory
+// (it follows the allocation handle through re-mappings, not the virtual address), it is constant over runs of 2-16 GB in
+// allocation order, and which run comes first differs from process to process: that is the "placement lottery" of round 1
+// (hipMalloc'ed output arrays sit back to back in one run about half of the time).  The most likely cause is the three ranks of
+// a 12-high HBM3E stack; nothing here depends on that interpretation.
+//
+// So this allocator does not search, it builds: memory is taken from the driver in 512 MB physical chunks (HIP virtual-memory
+// API), each new chunk is CLASSIFIED once by timing the store pattern into it together with a reference chunk of each known class
+// (same class: slow, different class: fast; ~1 ms per probe, footprint 1 GB so that the 256 MB Infinity Cache cannot hide it),
+// and the arrays of a set are laid out so that chunk i of array a has class (a + i) mod K: at every moment of a kernel that
+// sweeps all arrays of the set in step, the chunks being written are spread evenly over the classes.
+//
+// HIP virtual-memory hazards measured on ROCm 7.2 (tools/hazard_probe.hip) that shape the code:
+//  * after hipMemUnmap + hipMemMap of ANOTHER handle at a virtual address that was mapped before, kernels and hipMemcpy keep
+//    using the OLD physical memory.  Therefore no virtual range is ever mapped twice: ranges of freed buffers stay reserved
+//    (never handed back with hipMemAddressFree, which could return them from a later hipMemAddressReserve).  Costs address
+//    space only (47-bit space; a 72 GB set can be allocated ~1800 times per process).
+//  * one handle can be mapped at two addresses at once; a chunk keeps the "home" mapping it was classified through and is
+//    mapped a second time into the array it serves.
+// Chunks of freed buffers go back to a per-device pool (still classified) and are reused; crt_hip_buffer_trim releases them.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "crt1d_hip.h"
 
 namespace {
 
-struct Buffer {
-  size_t size;
-  std::vector<hipMemGenericAllocationHandle_t> handles;
+constexpr size_t CHUNK = 512ull << 20;
+constexpr int NCLS = 3;           // classes 0..2; 3 = ambiguous (a chunk that straddles two runs)
+constexpr int P_NZ = 60, P_NB = 300, P_T = 8;
+constexpr int P_COLS = (int)(CHUNK / ((size_t)P_NZ * P_NB * 8));  // 3728 columns of 144 000 B fill a chunk
+constexpr double SLOW_BELOW = 1.09;  // pair rate / single rate: same class ~1.00-1.02, different classes ~1.22-1.27
+constexpr double FAST_ABOVE = 1.15;
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// the store pattern of k_pipe / k_tri_pipe: workgroup = column, T levels of every array per round, 16 B per lane
+__global__ __launch_bounds__(512) void k_probe_cols(double* o0, double* o1, int na) {
+  const long long base = (long long)blockIdx.x * P_NZ * P_NB;
+  for (int j0 = 0; j0 < P_NZ; j0 += P_T) {
+    const int n2 = min(P_T, P_NZ - j0) * P_NB / 2;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+      d2 v;
+      v.x = 0.0;
+      v.y = 0.0;
+      reinterpret_cast<d2*>(o0 + base + (long long)j0 * P_NB)[i] = v;
+      if (na > 1) reinterpret_cast<d2*>(o1 + base + (long long)j0 * P_NB)[i] = v;
+    }
+  }
+}
+
+struct Chunk {
+  hipMemGenericAllocationHandle_t h;
+  char* home;  // the mapping it was classified through (kept for the life of the chunk)
+  int cls;
 };
+
+struct Pool {
+  std::vector<Chunk> free_chunks;
+  Chunk ref[NCLS];
+  int nref = 0;
+  double single_ms = 0.0;  // the pattern into one chunk alone
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  // statistics (crt_hip_buffer_stats)
+  long long created = 0, released = 0, probes = 0;
+  double probe_ms_total = 0.0;
+};
+
+struct Buffer {
+  size_t size;    // bytes reserved (multiple of CHUNK)
+  int dev;
+  std::vector<Chunk> chunks;
+};
+
 std::mutex g_mu;
+std::map<int, Pool> g_pools;
 std::map<void*, Buffer> g_buffers;
 
-constexpr size_t CHUNK = 1ull << 30;
-
-void release(void* va, Buffer& b, size_t mapped) {
-  if (mapped) (void)hipMemUnmap(va, mapped);
-  for (auto h : b.handles) (void)hipMemRelease(h);
-  (void)hipMemAddressFree(va, b.size);
+hipMemAllocationProp dev_prop(int dev) {
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  return prop;
 }
+
+bool set_access(void* va, size_t size, int dev) {
+  hipMemAccessDesc acc = {};
+  acc.location.type = hipMemLocationTypeDevice;
+  acc.location.id = dev;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  return hipMemSetAccess(va, size, &acc, 1) == hipSuccess;
+}
+
+// unmap a range for good: the reservation is deliberately kept (see the header comment)
+void retire_range(void* va, size_t size) { (void)hipMemUnmap(va, size); }
+
+void release_chunk(Pool& p, Chunk& c) {
+  if (c.home) retire_range(c.home, CHUNK);
+  (void)hipMemRelease(c.h);
+  c.home = nullptr;
+  ++p.released;
+}
+
+bool new_chunk(Pool& p, int dev, Chunk& c) {
+  hipMemAllocationProp prop = dev_prop(dev);
+  if (hipMemCreate(&c.h, CHUNK, &prop, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  void* va = nullptr;
+  if (hipMemAddressReserve(&va, CHUNK, 0, nullptr, 0) != hipSuccess) {
+    (void)hipMemRelease(c.h);
+    return false;
+  }
+  if (hipMemMap(va, CHUNK, 0, c.h, 0) != hipSuccess || !set_access(va, CHUNK, dev)) {
+    (void)hipMemRelease(c.h);
+    return false;
+  }
+  c.home = static_cast<char*>(va);
+  c.cls = NCLS;
+  ++p.created;
+  return true;
+}
+
+// average time of the store pattern into one or two chunks (null stream; the caller holds g_mu)
+double probe_ms(Pool& p, char* a, char* b) {
+  if (!p.e0) {
+    if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return -1.0;
+  }
+  const int na = b ? 2 : 1, reps = 3;
+  hipLaunchKernelGGL(k_probe_cols, dim3(P_COLS), dim3(512), 0, 0, reinterpret_cast<double*>(a), reinterpret_cast<double*>(b ? b : a), na);
+  (void)hipEventRecord(p.e0, 0);
+  for (int i = 0; i < reps; ++i)
+    hipLaunchKernelGGL(k_probe_cols, dim3(P_COLS), dim3(512), 0, 0, reinterpret_cast<double*>(a), reinterpret_cast<double*>(b ? b : a), na);
+  (void)hipEventRecord(p.e1, 0);
+  if (hipEventSynchronize(p.e1) != hipSuccess) return -1.0;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, p.e0, p.e1) != hipSuccess) return -1.0;
+  ++p.probes;
+  p.probe_ms_total += ms;
+  return ms / reps;
+}
+
+// class of a new chunk: the reference it is SLOW with.  A chunk that is fast with every known reference founds a new class and
+// becomes its (dedicated, never handed out) reference: returns false then, the chunk is consumed.
+bool classify(Pool& p, Chunk& c) {
+  if (p.nref == 0) {
+    (void)probe_ms(p, c.home, nullptr);  // first launches of the process: clocks and code object warm up
+    p.single_ms = probe_ms(p, c.home, nullptr);
+    c.cls = 0;
+    p.ref[p.nref++] = c;
+    return false;
+  }
+  bool all_fast = true;
+  for (int r = 0; r < p.nref; ++r) {
+    const double t = probe_ms(p, p.ref[r].home, c.home);
+    if (t <= 0 || p.single_ms <= 0) {
+      all_fast = false;
+      break;
+    }
+    const double ratio = 2.0 * p.single_ms / t;  // pair rate / single rate
+    if (ratio < SLOW_BELOW) {
+      c.cls = r;
+      return true;
+    }
+    if (ratio < FAST_ABOVE) all_fast = false;
+  }
+  if (all_fast && p.nref < NCLS) {
+    c.cls = p.nref;
+    p.ref[p.nref++] = c;
+    return false;
+  }
+  c.cls = NCLS;  // ambiguous: usable, but counted in no class
+  return true;
+}
+
+char cls_letter(int c) { return c < NCLS ? "XYZ"[c] : '?'; }
 
 }  // namespace
 
 extern "C" {
 
-int crt_hip_buffer_alloc(size_t bytes, void** ptr) {
-  if (!ptr || bytes == 0) return CRT_ERR_BAD_ARG;
-  *ptr = nullptr;
+int crt_hip_buffer_alloc_set(int32_t n, const size_t* bytes, void** ptrs) {
+  if (n <= 0 || n > 16 || !bytes || !ptrs) return CRT_ERR_BAD_ARG;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return CRT_ERR_LAUNCH;
-  hipMemAllocationProp prop = {};
-  prop.type = hipMemAllocationTypePinned;
-  prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = dev;
-  size_t gran = 0;
-  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0)
-    return CRT_ERR_UNSUPPORTED;
-  if (gran < (2u << 20)) gran = 2u << 20;  // keep 2 MB alignment of every mapping
-  Buffer b;
-  b.size = ((bytes + gran - 1) / gran) * gran;
-  void* va = nullptr;
-  if (hipMemAddressReserve(&va, b.size, 0, nullptr, 0) != hipSuccess) return CRT_ERR_WORKSPACE;
-  size_t off = 0;
-  while (off < b.size) {
-    const size_t c = b.size - off < CHUNK ? b.size - off : CHUNK;
-    hipMemGenericAllocationHandle_t h;
-    if (hipMemCreate(&h, c, &prop, 0) != hipSuccess) {
-      release(va, b, off);
-      return CRT_ERR_WORKSPACE;
-    }
-    b.handles.push_back(h);
-    if (hipMemMap(static_cast<char*>(va) + off, c, 0, h, 0) != hipSuccess) {
-      release(va, b, off);
-      return CRT_ERR_WORKSPACE;
-    }
-    off += c;
-  }
-  hipMemAccessDesc acc = {};
-  acc.location = prop.location;
-  acc.flags = hipMemAccessFlagsProtReadWrite;
-  if (hipMemSetAccess(va, b.size, &acc, 1) != hipSuccess) {
-    release(va, b, b.size);
-    return CRT_ERR_WORKSPACE;
+  std::vector<size_t> m(n);
+  size_t need = 0, rows = 0;
+  for (int a = 0; a < n; ++a) {
+    if (bytes[a] == 0) return CRT_ERR_BAD_ARG;
+    ptrs[a] = nullptr;
+    m[a] = (bytes[a] + CHUNK - 1) / CHUNK;
+    need += m[a];
+    rows = std::max(rows, m[a]);
   }
   std::lock_guard<std::mutex> lk(g_mu);
-  g_buffers[va] = std::move(b);
-  *ptr = va;
+  Pool& p = g_pools[dev];
+  // ---- gather chunks: the pool's free ones, then new ones until the selection can be balanced (or the cap is reached)
+  std::vector<Chunk> have;
+  have.swap(p.free_chunks);
+  auto count = [&](int c) { return (size_t)std::count_if(have.begin(), have.end(), [c](const Chunk& k) { return k.cls == c; }); };
+  auto balanced = [&]() {
+    if (have.size() < need) return false;
+    if (need < 2) return true;
+    size_t cnt[NCLS + 1];
+    size_t most = 0;
+    for (int c = 0; c <= NCLS; ++c) {
+      cnt[c] = count(c);
+      if (c < NCLS) most = std::max(most, cnt[c]);
+    }
+    // the classes other than the largest one can supply 40 % of the selection
+    return have.size() - most >= (need * 2 + 4) / 5;
+  };
+  // Gathering: first `need` chunks, whatever they are.  If they cannot be balanced (a process often starts inside a run of
+  // 10-35 GB of one class), hunt for another class: keep what we hold, put unmapped SPACER allocations of 1, 2, 4, 8 GB in
+  // front of the driver's allocation cursor and sample one chunk behind each, until the other classes can supply 40 % of
+  // the request or the exploration budget (memory held at one time) is spent.  Spacers and surplus chunks are released
+  // before returning; the whole hunt costs a few ms per sample.
+  size_t free0 = 0, tot0 = 0;
+  if (hipMemGetInfo(&free0, &tot0) != hipSuccess) free0 = need * CHUNK + (22ull << 30);
+  const size_t budget = std::min<size_t>(free0 > (6ull << 30) ? free0 - (6ull << 30) : 0, need * CHUNK + (112ull << 30));
+  std::vector<hipMemGenericAllocationHandle_t> spacers;
+  size_t spacer_bytes = 0, next_spacer = 1ull << 30;
+  int run = 0;
+  bool oom = false;
+  auto majority = [&]() {
+    int best = 0;
+    size_t nbest = 0;
+    for (int c = 0; c < NCLS; ++c) {
+      const size_t k = count(c);
+      if (k > nbest) { nbest = k; best = c; }
+    }
+    return best;
+  };
+  while (!balanced()) {
+    const size_t held = have.size() * CHUNK + spacer_bytes;
+    if (held + CHUNK > budget) {
+      if (have.size() < need) oom = true;
+      break;
+    }
+    if (have.size() >= need && run >= 2) {  // inside a run of the majority class: jump ahead
+      const size_t sp = std::min(next_spacer, budget - held - CHUNK);
+      if (sp >= (512ull << 20)) {
+        hipMemAllocationProp prop = dev_prop(dev);
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, sp, &prop, 0) == hipSuccess) {
+          spacers.push_back(h);
+          spacer_bytes += sp;
+          next_spacer = std::min<size_t>(next_spacer * 2, 8ull << 30);
+        } else {
+          (void)hipGetLastError();
+          break;
+        }
+      }
+    }
+    Chunk c;
+    if (!new_chunk(p, dev, c)) {
+      oom = have.size() < need;
+      break;
+    }
+    const int nref_before = p.nref;
+    if (classify(p, c)) {
+      have.push_back(c);
+      if (c.cls == majority()) ++run;
+      else { run = 0; next_spacer = 1ull << 30; }
+    } else if (p.nref > nref_before) {  // founded a new class (and became its reference): we are in another run now
+      run = 0;
+      next_spacer = 1ull << 30;
+    }
+  }
+  for (auto h : spacers) (void)hipMemRelease(h);
+  if (have.size() < need) {
+    p.free_chunks.swap(have);
+    return oom ? CRT_ERR_WORKSPACE : CRT_ERR_LAUNCH;
+  }
+  // ---- how many chunks of each class to use: as even as the supply allows
+  size_t avail[NCLS + 1], sel[NCLS + 1] = {0, 0, 0, 0};
+  for (int c = 0; c <= NCLS; ++c) avail[c] = count(c);
+  for (size_t k = 0; k < need; ++k) {  // water-filling: always take from the class used least so far that still has supply
+    int best = -1;
+    for (int c = 0; c < NCLS; ++c)
+      if (sel[c] < avail[c] && (best < 0 || sel[c] < sel[best])) best = c;
+    if (best < 0) best = NCLS;  // only ambiguous chunks left
+    ++sel[best];
+  }
+  // ---- interleave: slots in row-major order (chunk index i, array a); error diffusion over the classes, rotated per row
+  std::vector<std::vector<Chunk>> per(n);
+  double credit[NCLS + 1] = {0, 0, 0, 0};
+  size_t used[NCLS + 1] = {0, 0, 0, 0};
+  auto take = [&](int c) {
+    for (size_t k = 0; k < have.size(); ++k)
+      if (have[k].cls == c) {
+        Chunk ch = have[k];
+        have.erase(have.begin() + k);
+        return ch;
+      }
+    return Chunk{};  // unreachable: sel[] never exceeds the supply
+  };
+  for (size_t i = 0; i < rows; ++i)
+    for (int a = 0; a < n; ++a) {
+      if (i >= m[a]) continue;
+      int best = -1;
+      for (int c = 0; c <= NCLS; ++c) {
+        credit[c] += (double)sel[c] / (double)need;
+        if (used[c] < sel[c] && (best < 0 || credit[c] > credit[best] + 1e-12)) best = c;
+      }
+      credit[best] -= 1.0;
+      ++used[best];
+      per[a].push_back(take(best));
+    }
+  // ---- unselected chunks: newly gathered surplus goes back to the driver (keep a few for the next small request)
+  while (have.size() > 4) {
+    release_chunk(p, have.back());
+    have.pop_back();
+  }
+  p.free_chunks.swap(have);
+  // ---- map every array into a fresh virtual range (second mapping of its chunks)
+  for (int a = 0; a < n; ++a) {
+    const size_t size = m[a] * CHUNK;
+    void* va = nullptr;
+    bool ok = hipMemAddressReserve(&va, size, 0, nullptr, 0) == hipSuccess;
+    size_t mapped = 0;
+    for (size_t i = 0; ok && i < m[a]; ++i) {
+      ok = hipMemMap(static_cast<char*>(va) + i * CHUNK, CHUNK, 0, per[a][i].h, 0) == hipSuccess;
+      if (ok) mapped += CHUNK;
+    }
+    ok = ok && set_access(va, size, dev);
+    if (!ok) {
+      if (va && mapped) retire_range(va, mapped);
+      for (int b = a; b < n; ++b)
+        for (auto& c : per[b]) p.free_chunks.push_back(c);
+      for (int b = 0; b < a; ++b) {  // undo the arrays already built
+        auto it = g_buffers.find(ptrs[b]);
+        if (it != g_buffers.end()) {
+          retire_range(ptrs[b], it->second.size);
+          for (auto& c : it->second.chunks) p.free_chunks.push_back(c);
+          g_buffers.erase(it);
+        }
+        ptrs[b] = nullptr;
+      }
+      (void)hipGetLastError();
+      return CRT_ERR_WORKSPACE;
+    }
+    Buffer b;
+    b.size = size;
+    b.dev = dev;
+    b.chunks = std::move(per[a]);
+    g_buffers[va] = std::move(b);
+    ptrs[a] = va;
+  }
   return CRT_OK;
 }
 
+int crt_hip_buffer_alloc(size_t bytes, void** ptr) {
+  if (!ptr || bytes == 0) return CRT_ERR_BAD_ARG;
+  return crt_hip_buffer_alloc_set(1, &bytes, ptr);
+}
+
 int crt_hip_buffer_free(void* ptr) {
-  Buffer b;
-  {
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_buffers.find(ptr);
-    if (it == g_buffers.end()) return CRT_ERR_BAD_ARG;
-    b = std::move(it->second);
-    g_buffers.erase(it);
-  }
-  release(ptr, b, b.size);
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_buffers.find(ptr);
+  if (it == g_buffers.end()) return CRT_ERR_BAD_ARG;
+  Buffer b = std::move(it->second);
+  g_buffers.erase(it);
+  retire_range(ptr, b.size);
+  Pool& p = g_pools[b.dev];
+  for (auto& c : b.chunks) p.free_chunks.push_back(c);
+  return CRT_OK;
+}
+
+int crt_hip_buffer_trim(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return CRT_ERR_LAUNCH;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_pools.find(dev);
+  if (it == g_pools.end()) return CRT_OK;
+  for (auto& c : it->second.free_chunks) release_chunk(it->second, c);
+  it->second.free_chunks.clear();
+  return CRT_OK;
+}
+
+int crt_hip_buffer_describe(const void* ptr, char* buf, size_t n) {
+  if (!buf || n == 0) return CRT_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_buffers.find(const_cast<void*>(ptr));
+  if (it == g_buffers.end()) return CRT_ERR_BAD_ARG;
+  size_t k = 0;
+  for (auto& c : it->second.chunks)
+    if (k + 1 < n) buf[k++] = cls_letter(c.cls);
+  buf[k] = 0;
+  return CRT_OK;
+}
+
+int crt_hip_buffer_stats(int64_t* out6) {
+  if (!out6) return CRT_ERR_BAD_ARG;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return CRT_ERR_LAUNCH;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Pool& p = g_pools[dev];
+  out6[0] = p.created;
+  out6[1] = p.released;
+  out6[2] = p.probes;
+  out6[3] = (int64_t)(p.probe_ms_total * 1000.0);  // microseconds of GPU time spent classifying
+  out6[4] = (int64_t)p.free_chunks.size();
+  out6[5] = p.nref;
   return CRT_OK;
 }
 

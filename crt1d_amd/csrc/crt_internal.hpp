@@ -80,7 +80,16 @@ struct SolveArgs {
   void* o[7];  // I_dr, I_df_d, I_df_u, F, x0, x1, x2
   double mu_s;
   int f32;     // 0: TIO = double, 1: TIO = float
+  // kernel-selection overrides of THIS call (crt_options.tune; 0 = automatic): [0] LDS bytes a closed-form tile may take,
+  // [1] force T of k_tile, [2] flags (bit0 __syncthreads barriers, bit1 generic flush, bit2 no pipeline, bit3 no generic-flush
+  // pipeline), [3] store waves of k_pipe, [4] T of k_pipe; [8] M, [9] T, [10] kernel family, [11] store waves of the tridiagonal
+  // kernels (tri_tile_impl.hpp)
+  int tune[CRT_NTUNE];
 };
+
+// name of the solve kernel the last launch_* call of this thread chose (crt_hip_last_kernel; reporting only)
+void note_kernel(const char* fmt, ...);
+const char* last_kernel();
 
 template <typename TIO>
 __device__ inline double ldio(const void* p, long long i) {
@@ -362,8 +371,6 @@ int launch_closed(int scheme, const SolveArgs& a, hipStream_t s, int force);
 int launch_tridiag(int scheme, const SolveArgs& a, hipStream_t s, int force);
 int init_quadrature(hipStream_t s);
 int launch_tau_d(const double* kb_nodes, const double* L, long long n, int method, double* out, hipStream_t s);
-void tune_closed(int key, int value);
-void tune_tridiag(int key, int value);
 int launch_tridiag_tile(int scheme, const SolveArgs& a, hipStream_t s, bool& done);
 // per-(scheme, storage type) instantiation units: tri_inst.hip compiled four times
 int launch_tri_tile_n79_f64(const SolveArgs& a, hipStream_t s, bool& done);

@@ -48,6 +48,7 @@ __device__ inline BandIn load_band(const SolveArgs& a, int c, int b, bool need_s
 // ------------------------------------------------------------------------------------------
 // 2s  Dickinson-Sellers two-stream (crt1d/solvers/_solve_2s.py:54-156)
 struct Sch2s {
+  static constexpr const char* NAME = "2s";
   static constexpr int NARR = 4;
   static constexpr bool SOIL = true;
   static constexpr bool HEAVY_INIT = false;
@@ -134,6 +135,7 @@ struct Sch2s {
 // ------------------------------------------------------------------------------------------
 // bl  Beer-Lambert (crt1d/solvers/_solve_bl.py:51-90)
 struct SchBl {
+  static constexpr const char* NAME = "bl";
   static constexpr int NARR = 4;
   static constexpr bool SOIL = false;
   static constexpr bool HEAVY_INIT = false;
@@ -167,6 +169,7 @@ struct SchBl {
 // (crt1d/solvers/_solve_bf.py:60-140): same inputs/outputs, different scattered-light terms.
 template <bool BF>
 struct SchG77 {
+  static constexpr const char* NAME = BF ? "bf" : "g77";
   static constexpr int NARR = 7;
   static constexpr bool SOIL = true;
   static constexpr bool HEAVY_INIT = false;
@@ -295,6 +298,7 @@ __device__ inline void solve4(double (&A)[4][5]) {
 }
 
 struct Sch4s {
+  static constexpr const char* NAME = "4s";
   static constexpr int NARR = 4;
   static constexpr bool SOIL = true;
   static constexpr bool HEAVY_INIT = true;  // eigen-decomposition + 4x4 solve per band before the first level: wants more workgroups per CU
@@ -734,11 +738,11 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
 
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_DIRECT_LDS = 64 * 1024;
-// tunables (crt_hip_tune): [0] LDS bytes a tile may take per workgroup, [1] force T (0 = automatic),
+// tunables (crt_options.tune, per call): [0] LDS bytes a tile may take per workgroup, [1] force T (0 = automatic),
 // [2] TileCfg.flags (bit0: __syncthreads barriers, bit1: generic instead of fused flush).  Measured on MI355X, 2s at 1e4 x 300 x 60 (tools/ab_tile.py, interleaved rounds):
 //   T=2 (not line aligned) 1.66 ms | T=4, 4 WG/CU 1.20 ms | T=8, 2 WG/CU 1.03 ms | T=12, 1 WG/CU 1.25 ms
 // -> take the longest line-aligned run that still leaves two workgroups resident per CU (160 KB LDS).
-int g_tune[8] = {78 * 1024, 0, 0, 0, 0, 0, 0, 0};
+constexpr int DEFAULT_TILE_LDS = 78 * 1024;
 
 int gcd(int x, int y) { return y ? gcd(y, x % y) : x; }
 
@@ -746,6 +750,9 @@ template <class S, typename TIO>
 int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
   done = false;
   const int nb = a.nb;
+  int g_tune[8];  // this call's overrides (crt_options.tune); [0] = 0 means the default LDS budget
+  for (int i = 0; i < 8; ++i) g_tune[i] = a.tune[i];
+  if (g_tune[0] <= 0) g_tune[0] = DEFAULT_TILE_LDS;
   if (nb < 64 || nb > 1024) return CRT_OK;
   const int CB = nb <= 256 ? 256 / nb : 1;
   const int nthr = CB > 1 ? 256 : ((nb + 63) / 64) * 64;
@@ -814,6 +821,7 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh) != hipSuccess)
           return (int)CRT_ERR_LAUNCH;
         hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(pthr), psh, s, a, pc);
+        note_kernel("k_pipe<%s,%s>%s T=%d store_waves=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", fused ? "" : " generic-flush", Tp, nsw, psh);
         return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
       };
       int st;
@@ -828,6 +836,7 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nthr), sh, s, a, cfg);
+    note_kernel("k_tile<%s,%s>%s CB=%d T=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", fused ? "" : " generic-flush", CB, T, sh);
     return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
   };
   int st;
@@ -850,6 +859,7 @@ int launch_direct_v(const SolveArgs& a, size_t lds_bytes, hipStream_t s) {
   const long long nblk = (items + DBLOCK - 1) / DBLOCK;
   if (nblk > 0x7fffffffLL) return CRT_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((k_direct<S, TIO, VEC, USE_LDS>), dim3((unsigned)nblk), dim3(DBLOCK), USE_LDS ? lds_bytes : 0, s, a);
+  note_kernel("k_direct<%s,%s> VEC=%d", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", VEC);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 
@@ -934,6 +944,7 @@ int launch_int(const SolveArgs& a, const IntArgs& ia, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, ia, rec_dbl);
+    note_kernel("k_int<%s>%s", S::NAME, rows ? " row partials" : " wave totals");
     return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
   };
   if (rows) {
@@ -962,10 +973,6 @@ int launch_closed_int(int scheme, const SolveArgs& a, const IntArgs& ia, hipStre
     case CRT_SCHEME_BF: return launch_int_io<SchG77<true>>(a, ia, s);
     default: return CRT_ERR_BAD_ARG;
   }
-}
-
-void tune_closed(int key, int value) {
-  if (key >= 0 && key < 8) g_tune[key] = value;
 }
 
 // force: 0 = pick (tile when it applies), 1 = direct-store kernel (kept selectable for A/B measurements)

@@ -172,6 +172,7 @@ int launch_wave(const SolveArgs& a, hipStream_t s) {
     const int st = set_lds_limit(kern, sh);
     if (st != CRT_OK) return st;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(TB), sh, s, a, (int)rec_doubles);
+    note_kernel("k_tri_wave<%s,%s> pairs in %s", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", ef_in_lds ? "LDS" : "output rows");
     return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
   };
   if (ef_in_lds) return use_lds ? go(k_tri_wave<S, TIO, true, EfLds>) : go(k_tri_wave<S, TIO, false, EfLds>);

@@ -4,11 +4,20 @@
 
 namespace crt {
 
-int g_tri_tune[4] = {0, 0, 0, 0};  // crt_hip_tune keys 8..11, see tri_tile_impl.hpp
+#include <stdarg.h>
+#include <stdio.h>
 
-void tune_tridiag(int key, int value) {
-  if (key >= 0 && key < 4) g_tri_tune[key] = value;
+namespace {
+thread_local char g_last_kernel[192] = "";
 }
+
+void note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_kernel, sizeof g_last_kernel, fmt, ap);
+  va_end(ap);
+}
+const char* last_kernel() { return g_last_kernel; }
 
 int launch_tridiag_int(int scheme, const SolveArgs& a, const IntArgs& ia, hipStream_t s) {
   if (scheme == CRT_SCHEME_N79) return a.f32 ? launch_tri_int_n79_f32(a, ia, s) : launch_tri_int_n79_f64(a, ia, s);

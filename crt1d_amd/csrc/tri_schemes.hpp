@@ -11,6 +11,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------
 // n79 (crt1d/solvers/_solve_n79.py:70-155).  Even row k <-> upward flux at level k, k = 0 .. nz-1.
 struct TriN79 {
+  static constexpr const char* NAME = "n79";
   static constexpr int NST = 4;   // staged: dn, up, aI_lsl, aI_lsh
   static constexpr int NOUT = 6;  // I_dr, I_df_d, I_df_u, F, aI_lsl, aI_lsh
   double swb, swd, rho, tau, alb, oma, invmu, irho;
@@ -182,6 +183,7 @@ struct UniformOf<TriN79> {
 // ------------------------------------------------------------------------------------------
 // zq (crt1d/solvers/_solve_zq.py:74-219).  Even row k <-> SWu0[k], k = 0 .. m (m = nz); output level z = k, k < m.
 struct TriZq {
+  static constexpr const char* NAME = "zq";
   static constexpr int NST = 4;   // staged: I_df_d, I_df_u, I_df_d_ss, I_df_u_ss
   static constexpr int NOUT = 7;  // I_dr, I_df_d, I_df_u, F, I_df_d_ss, I_df_u_ss, F_ss
   double I_dr0, I_df0, rho, fwd, q, q0, cu, cd, invmu;
@@ -285,6 +287,7 @@ struct TriZq {
 // zq_pa computational-grid solve (crt1d/solvers/_solve_zq_pa.py:24-418): the zq system with nz := M, only the two
 // single-scattering interface fluxes are kept (see tri_zqpa.hip, launch_zqpa).
 struct TriZqPa : TriZq {
+  static constexpr const char* NAME = "zq_pa grid";
   static constexpr int NOUT = 2;
   __host__ __device__ static inline int out_rows(int, int nz) { return nz; }
   template <int ARR>

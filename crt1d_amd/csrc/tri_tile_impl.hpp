@@ -27,7 +27,6 @@
 #include "tri_schemes.hpp"
 
 namespace crt {
-extern int g_tri_tune[4];
 namespace {
 
 constexpr size_t MAX_WG_LDS = 160 * 1024;
@@ -254,6 +253,7 @@ int launch_mt(const SolveArgs& a, hipStream_t s, int nthr) {
     hipLaunchKernelGGL((k_tri_tile<S, TIO, M, T, 512, FUSED>), grid, block, sh, s, a, cfg);
   else
     hipLaunchKernelGGL((k_tri_tile<S, TIO, M, T, 1024, FUSED>), grid, block, sh, s, a, cfg);
+  note_kernel("k_tri_tile<%s,%s>%s M=%d T=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", FUSED ? "" : " generic-flush", M, T, sh);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 
@@ -359,6 +359,7 @@ int launch_int_m(const SolveArgs& a, const IntArgs& ia, hipStream_t s, int nthr)
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, ia, off_ck, off_int);
+    note_kernel("k_tri_int<%s> M=%d", S::NAME, M);
     return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
   };
   if (nthr <= 256) return go(k_tri_int<S, TIO, M, 256>);
@@ -375,7 +376,7 @@ int launch_int_scheme(const SolveArgs& a, const IntArgs& ia, hipStream_t s) {
   return st;
 }
 
-// tune keys 8..11 (crt_hip_tune): [0] force M (8/12/16), [1] force T (4/8), [2] kernel family, [3] store waves; defined in solve_tridiag_tile.hip
+// crt_options.tune[8..11]: [8] force M (8/12/16), [9] force T (4/8), [10] kernel family, [11] store waves
 
 // instantiated (M, T) pairs
 template <class S, typename TIO, bool FUSED>
@@ -676,6 +677,7 @@ int launch_pipe_generic(const SolveArgs& a, hipStream_t s, int nstore_waves) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
     return CRT_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, cfg);
+  note_kernel("k_tri_pipe<%s,%s> generic-flush M=%d T=%d store_waves=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", M, T, nstore_waves, sh);
   return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
 }
 
@@ -699,6 +701,8 @@ int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves, bool reg
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, cfg);
+    note_kernel("k_tri_pipe<%s,%s> %s M=%d T=%d store_waves=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32",
+                regstage ? "register-staged" : "double-buffered", M, T, nstore_waves, sh);
     return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
   };
   if (regstage) return nthr <= 512 ? go(k_tri_pipe<S, TIO, M, T, 512, PIPE_RS>) : go(k_tri_pipe<S, TIO, M, T, 1024, PIPE_RS>);
@@ -717,6 +721,7 @@ int launch_pipe(const SolveArgs& a, hipStream_t s, int M, int T, int nsw, bool r
 template <class S, typename TIO>
 int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 64) {
   done = false;
+  const int* g_tri_tune = a.tune + 8;  // this call's overrides (crt_options.tune[8..11])
   if (a.nb < min_nb || a.nb > 1024) return CRT_OK;  // narrow spectra: the per-wave kernels fill their lanes better
   const int nthr = ((a.nb + 63) / 64) * 64;
   const int K = S::rows(a.nz);

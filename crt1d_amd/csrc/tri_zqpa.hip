@@ -197,6 +197,7 @@ int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, g, cfg);
+    note_kernel("k_zqpa_pipe<%s> M=%d T=%d store_waves=%d lds=%zu", sizeof(TIO) == 8 ? "f64" : "f32", M, T, nsw, sh);
     return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
   };
   return nthr <= 512 ? go(k_zqpa_pipe<TIO, M, T, 512>) : go(k_zqpa_pipe<TIO, M, T, 1024>);
@@ -205,6 +206,7 @@ int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
 }  // namespace
 
 int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s) {
+  const int* g_tri_tune = a.tune + 8;  // this call's overrides
   if (g_tri_tune[2] != 1 || a.f32) {  // fused interpolation first (tune key 10 = 1: the two-kernel path with workspace scratch)
     const int nsw = g_tri_tune[3];
     int st;
@@ -245,6 +247,7 @@ int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
     return CRT_ERR_LAUNCH;
   hipLaunchKernelGGL((k_zqpa_interp<double>), dim3(a.ncol), dim3(256), sh, s, ia);
+  note_kernel("zq_pa two-kernel path: grid solve + k_zqpa_interp");
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 

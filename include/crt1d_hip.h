@@ -27,7 +27,9 @@
  *    arrays, stacked over columns).
  *  - return value: 0 on success, negative crt_status otherwise (the Python wrapper maps these
  *    to the reference's exception types: AssertionError / ValueError).
- *  - thread-safety: re-entrant; concurrent calls must use distinct streams + workspaces.
+ *  - thread-safety: re-entrant -- no mutable process-global state on the solve path (kernel-selection overrides travel in
+ *    crt_options.tune; the quadrature tables are uploaded once per device under a lock); concurrent calls must use distinct
+ *    streams + workspaces.  The buffer allocator (crt_hip_buffer_*) serialises on one mutex.
  */
 #ifndef CRT1D_HIP_H
 #define CRT1D_HIP_H
@@ -39,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 1
+#define CRT_ABI_VERSION 2
 
 /* leaf-angle G(psi) kinds: crt1d/leaf_angle.py:118-202 */
 enum crt_g_kind {
@@ -107,10 +109,15 @@ typedef struct crt_bands {
 #define CRT_FLAG_DIRECT_STORES 4   /* measurement aid: use the direct-store solve kernel even where the LDS-tiled,
                                       line-aligned one applies (same results, different store pattern) */
 
+#define CRT_NTUNE 12
 typedef struct crt_options {
   double mu_s;            /* 4s: cosine of the dividing angle, default 0.501 (_solve_4s.py:9) */
   int32_t tau_d_method;   /* n79: crt_tau_d_method, default CRT_TAU_D_QUAD (_solve_n79.py:19) */
   int32_t flags;          /* CRT_FLAG_* */
+  int32_t tune[CRT_NTUNE];/* measurement aid, all zero in production: per-CALL overrides of the kernel-selection heuristics
+                             (tile height, store waves, kernel family; keys in csrc/crt_internal.hpp).  Part of the call's
+                             arguments, so there is no process-global tuning state: calls with different settings may run
+                             concurrently */
 } crt_options;
 
 /* outputs; each [ncol][nz][nb] unless noted.  Unused slots may be NULL. */
@@ -238,16 +245,29 @@ int crt_hip_lai_beta_f64(const double* h_c, const double* LAI, const double* h_m
                          double* lad, crt_stream_t stream);
 
 /*
- * Device buffers for the output profiles (optional; any device pointer works with the solve entry points).  Built with the HIP
- * virtual-memory API from 1 GB physical allocations: the solve kernels' store pattern runs 2-3 % faster into them than into
- * hipMalloc memory of the same region (tools/vmm_bw.hip).  The buffer belongs to the current device; free it with
- * crt_hip_buffer_free after all work that uses it has completed.  No counterpart in the reference (NumPy owns its arrays).
+ * Device buffers for the output profiles, with a deterministic placement in HBM (optional; any device pointer works with the
+ * solve entry points).  On MI355X the store pattern of the solve kernels runs at ~5.5 TB/s when all the memory written at one
+ * time lies in one "class" of physical memory and at ~7 TB/s when it is spread over two or three (csrc/buffers.hip explains the
+ * measurement).  crt_hip_buffer_alloc_set allocates the n arrays of one output set from 512 MB physical chunks (HIP
+ * virtual-memory API), classifies every new chunk with a ~1 ms probe, and interleaves the classes across the arrays so that a
+ * kernel sweeping all n arrays in step always writes a balanced mix.  ptrs[a] receives a device pointer to at least bytes[a]
+ * bytes (2 MB aligned).  Buffers belong to the current device; free each with crt_hip_buffer_free after all work that uses it
+ * has completed (its chunks return to a per-device pool; crt_hip_buffer_trim hands the pool's memory back to the driver).
+ * Synchronous (like hipMalloc); may run short probe kernels on the null stream.  No counterpart in the reference (NumPy owns
+ * its arrays).  crt_hip_buffer_alloc = a set of one.
+ * crt_hip_buffer_describe writes one letter per chunk of a buffer (X / Y / Z = class, ? = ambiguous) into buf;
+ * crt_hip_buffer_stats fills {chunks created, chunks released, probes run, probe microseconds, free chunks, classes seen}.
  */
+int crt_hip_buffer_alloc_set(int32_t n, const size_t* bytes, void** ptrs);
 int crt_hip_buffer_alloc(size_t bytes, void** ptr);
 int crt_hip_buffer_free(void* ptr);
+int crt_hip_buffer_trim(void);
+int crt_hip_buffer_describe(const void* ptr, char* buf, size_t n);
+int crt_hip_buffer_stats(int64_t* out6);
 
-/* measurement aid (not for production use): override kernel-selection heuristics, see solve_closed.hip */
-void crt_hip_tune(int key, int value);
+/* name and configuration of the solve kernel chosen by the calling thread's most recent solve / integrated call
+ * (e.g. "k_pipe<2s,f64> T=8 store_waves=3 lds=81536"); reporting only, valid until the thread's next call */
+const char* crt_hip_last_kernel(void);
 
 /* bandwidth probes used by bench.py to report a measured HBM ceiling next to the 8 TB/s spec */
 int crt_hip_probe_fill_f64(double* dst, size_t n, double value, crt_stream_t stream);

@@ -21,6 +21,11 @@ g5_4s_tight  default case, 4s with solve_bvp tol 1e-11 (the reference's stock to
 g7_options   mu_s in {0.501, 0.33998}; G_fn in {spherical, horizontal, vertical, ellipsoidal x in {0.5,1,2}, bonan}
 g8_leaf_area reference leaf_area.distribute_lai_beta(h_c, LAI, n, h_min=...) for 8 canopies (lai, lad, z)
 g9_common    reference solvers.common: tau_b_fn, tau_df_fn ('quad' and '9sky'), K_df_fn for 5 leaf-angle functions
+g6_absorption reference model._calc_absorption (model.py:573-647) on the reference solvers' own profiles (default case: 2s, n79,
+             zq; the 12 ragged columns of g4: 2s), reference spectra._x_frac_in_bounds weights (spectra.py:71-126) for PAR / NIR /
+             UV / solar on the default and the synthetic edges, and the band sums of diagnostics.py:81 formed with those weights.
+             ``crt1d.model`` / ``crt1d.spectra`` cannot be imported (top-level ``import xarray``); the two FUNCTIONS are compiled
+             from their definitions in the reference files where they lie (ast) and run here -- nothing is copied.
 """
 
 import argparse
@@ -268,6 +273,77 @@ def g9(la, out):
     print("wrote", out / "g9_common.npz")
 
 
+def reference_functions(path, names):
+    """Compile the named top-level function definitions / assignments of a reference source file (build container only) without
+    importing the module (its top-level ``import xarray`` fails here with an ordinary ModuleNotFoundError)."""
+    import ast
+    import warnings as _w
+
+    src = (REF / path).read_text()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name in names)
+            or (isinstance(n, ast.Assign) and any(isinstance(t, ast.Name) and t.id in names for t in n.targets))]
+    assert len(keep) == len(names), [getattr(n, "name", None) for n in keep]
+    ns = {"np": np, "warnings": _w}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), str(REF / path), "exec"), ns)
+    return ns
+
+
+def g6(la, lar, sol, out):
+    """Row a11/a12: the reference's own `_calc_absorption` and `_x_frac_in_bounds` outputs."""
+    calc = reference_functions("crt1d/model.py", ["_calc_absorption"])["_calc_absorption"]
+    sp = reference_functions("crt1d/spectra.py", ["_x_frac_in_bounds", "BAND_DEFNS_UM"])
+    xfrac, defs = sp["_x_frac_in_bounds"], sp["BAND_DEFNS_UM"]
+    KEYS = ("aI", "aI_df", "aI_dr", "aI_sh", "aI_sl", "aI_df_sl", "aI_df_sh", "laim", "f_slm")
+    p = default_case_inputs(la, lar)
+    lai = p["lai"]
+    p["dlai"] = lai[:-1] - lai[1:]  # model.py:248
+    p["K_b"] = p["K_b_fn"](p["psi"])  # model.py:293
+    wle = np.r_[p["wl"][0] - 0.5 * p["dwl"][0], p["wl"] + 0.5 * p["dwl"]]  # model.py:287
+    arrays = dict(psi=p["psi"], lai=lai, x=p["orient"], leaf_r=p["leaf_r"], leaf_t=p["leaf_t"], wle=wle, K_b=p["K_b"])
+    names = ("PAR", "NIR", "UV", "solar")
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # UV bounds extend below the data range: the reference warns, by design
+        W = np.stack([xfrac(wle, defs[n]) for n in names])
+    arrays["band_names"] = np.array(names)
+    arrays["band_bounds"] = np.array([defs[n] for n in names])
+    arrays["w_default"] = W
+    from types import SimpleNamespace
+
+    for s in ("2s", "n79", "zq"):
+        r = run_scheme(sol, s, p)
+        m = SimpleNamespace(_p=p, out={k: r[k] for k in ("I_dr", "I_df_d", "I_df_u")})
+        ab = calc(m)
+        # (the profiles themselves are the ones stored in g1_default.npz: same solver, same inputs, deterministic)
+        for k in KEYS:
+            arrays[f"{s}__{k}"] = ab[k]
+        # diagnostics.py:81  ds[vn] = (da * w).sum(dim="wl")  -- formed here with NumPy on the reference's weights and arrays
+        for k in ("aI", "aI_sl", "aI_sh"):
+            arrays[f"{s}__{k}__bandsum"] = np.stack([(ab[k] * w).sum(axis=-1) for w in W])
+        print("  g6", s)
+    # ragged synthetic columns (the reference solver outputs already stored in g4) -> per-column _calc_absorption
+    g4 = np.load(out / "g4_ragged.npz")
+    ncol = g4["psi"].shape[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        arrays["w_synth"] = np.stack([xfrac(g4["wle"], defs[n]) for n in names])
+    res = {k: [] for k in KEYS}
+    for c in range(ncol):
+        x = g4["g_param"][c]
+        lai_c = g4["lai"][c]
+        pc = dict(lai=lai_c, dlai=lai_c[:-1] - lai_c[1:], K_b=la.G_ellipsoidal_approx(float(g4["psi"][c]), x) / np.cos(float(g4["psi"][c])),
+                  leaf_r=g4["leaf_r"][c], leaf_t=g4["leaf_t"][c])
+        m = SimpleNamespace(_p=pc, out={k: g4[f"2s__{k}"][c] for k in ("I_dr", "I_df_d", "I_df_u")})
+        ab = calc(m)
+        for k in KEYS:
+            res[k].append(ab[k])
+    for k in KEYS:
+        arrays[f"ragged2s__{k}"] = np.stack(res[k])
+    save(out, "g6_absorption", **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(REPO / "tests" / "golden"))
@@ -305,6 +381,8 @@ def main():
         synth_case(la, sol, out, "g3_uniform", 12, 10, 60, True, ["2s", "4s", "bf", "bl", "g77", "n79", "zq", "zq_pa"], True)
     if want("g4"):
         synth_case(la, sol, out, "g4_ragged", 12, 10, 40, False, ["2s", "4s", "bf", "bl", "g77", "n79", "zq", "zq_pa"], True)
+    if want("g6"):
+        g6(la, lar, sol, out)
     if want("g7"):
         g7(la, lar, sol, out)
     if want("g8"):

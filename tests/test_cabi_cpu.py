@@ -41,14 +41,15 @@ def test_struct_layouts_match_header(lib):
 
     assert ctypes.sizeof(_lib.CrtColumns) == 8 + 7 * 8
     assert ctypes.sizeof(_lib.CrtBands) == 8 + 8 + 5 * 8
-    assert ctypes.sizeof(_lib.CrtOptions) == 16
+    assert ctypes.sizeof(_lib.CrtOptions) == 16 + 4 * _lib.NTUNE  # mu_s, tau_d_method, flags, tune[CRT_NTUNE]
     assert ctypes.sizeof(_lib.CrtOutputs) == 7 * 8
 
 
 def test_host_only_entry_points(lib):
     from crt1d_amd import _lib
 
-    assert lib.crt_hip_abi_version() == 1
+    assert lib.crt_hip_abi_version() == 2
+    assert isinstance(lib.crt_hip_last_kernel(), bytes)  # reporting hook; empty before the first solve
     assert _lib.strerror(0) == "ok" and "workspace" in _lib.strerror(_lib.CRT_ERR_WORKSPACE)
     # record = 16-double header + nvec * nz
     assert lib.crt_hip_workspace_bytes(_lib.SCHEME_IDS["2s"], 10, 60) == 10 * (16 + 2 * 60) * 8

@@ -128,3 +128,70 @@ def test_band_and_column_partition_world2(scheme):
     tot = ref["totals"].numpy()[:, 2]
     canopy = ref["aI"].numpy()[:, :, 2].sum(axis=1)
     np.testing.assert_allclose(tot[:, 0] - tot[:, 1] - (tot[:, 2] - tot[:, 3]), canopy, rtol=1e-10)
+
+
+def _plan_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from crt1d_amd.dist import BandShardPlan
+
+        d, bw = _problem()
+        solve_fn, epi = _oracle_fns()
+        plan = BandShardPlan("2s", HostCols(d), HostBands(d), bw, column_tiles=3, solve_fn=solve_fn, epilogue_fn=epi)
+        r1 = {k: v.clone() for k, v in plan().wait().items() if k in ("aI", "totals", "reflectance")}
+        r2 = plan().wait()  # the same plan again: buffers reused, same answer (steady-state use, bench.py --partition band)
+        r2 = {k: r2[k].numpy().copy() for k in r1}
+        local = plan(reduce=False).wait()  # compute-only: this rank's partial sums, NOT the full integral
+        q.put((rank, plan.band_range, plan.message_bytes, plan.ntile, {k: r1[k].numpy() for k in r1}, r2, float(local["totals"].sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_band_shard_plan_is_reusable_world2():
+    from crt1d_amd.dist import solve_sharded
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d, bw = _problem()
+    solve_fn, epi = _oracle_fns()
+    ref = solve_sharded("2s", HostCols(d), HostBands(d), bw, partition="column", solve_fn=solve_fn, epilogue_fn=epi)
+    ng = bw.shape[0]
+    nbytes = 8 * (3 * NCOL * (NZ - 1) * ng + NCOL * ng * 4)
+    partial = []
+    for rank, band_range, msg_bytes, ntile, r1, r2, local_sum in got:
+        assert band_range == ((0, 5) if rank == 0 else (5, 9)) and ntile == 3 and msg_bytes == nbytes
+        for k in r1:
+            np.testing.assert_allclose(r1[k], ref[k].numpy(), rtol=1e-12, atol=1e-13)
+            np.testing.assert_array_equal(r1[k], r2[k])
+        partial.append(local_sum)
+    np.testing.assert_allclose(sum(partial), float(ref["totals"].sum()), rtol=1e-12)
+
+
+def test_bench_launcher_spawns_ranks_itself():
+    """`python bench.py --gpus 2` without torch.distributed.run: the parent starts the two ranks as children (RANK / WORLD_SIZE /
+    MASTER_* set, rendezvous on 127.0.0.1) and rank 0 prints the one JSON line.  --launch-check stops before any GPU work."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out == {"launch_check": True, "n_gpus": 2, "ranks_seen": 2, "master": "127.0.0.1"}
+    # ranks that fail make the launcher fail (here: an argument the ranks reject)
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--partition", "nonsense"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert bad.returncode != 0

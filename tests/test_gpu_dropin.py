@@ -318,8 +318,7 @@ def test_model_to_dataset():
         assert set(m.to_xr().data_vars) == expected
 
 
-# (tune key, value) settings that select each kernel family through crt_hip_tune (keys: solve_closed.hip g_tune, solve_tridiag_tile.hip
-# g_tri_tune = keys 8..11)
+# (tune key, value) settings that select each kernel family through crt_options.tune (per call; keys in csrc/crt_internal.hpp)
 _CLOSED_PATHS = {"k_pipe (default)": {}, "k_tile": {2: 4}, "k_tile generic flush": {2: 4 | 2}, "k_pipe generic flush": {2: 2},
                  "k_pipe 1 store wave, T=2": {3: 1, 4: 2}, "k_pipe 4 store waves, T=8": {3: 4, 4: 8}}
 _TRI_PATHS = {"default": {}, "k_tri_tile": {10: 1}, "k_tri_tile M8 T8": {10: 1, 8: 8, 9: 8}, "double-buffer pipeline": {10: 2},
@@ -336,7 +335,6 @@ def test_every_kernel_family_gives_the_same_bits(scheme, shape, dtype):
 
     from crt1d_amd import _lib, batched, synth
 
-    lib = _lib.load()
     ncol, nb, nz = shape
     d = synth.make_columns(ncol, nb, nz, seed=13, uniform_dlai=(ncol % 2 == 1))
     if dtype == "f32":
@@ -345,45 +343,46 @@ def test_every_kernel_family_gives_the_same_bits(scheme, shape, dtype):
     ref = batched.Plan(scheme, cols, bands)
     ref(flags=_lib.FLAG_DIRECT_STORES)
     paths = _TRI_PATHS if scheme in ("n79", "zq") else _CLOSED_PATHS
-    keys = sorted({k for t in paths.values() for k in t})
-    try:
-        for name, tune in paths.items():
-            for k in keys:
-                lib.crt_hip_tune(k, tune.get(k, 0))
-            p = batched.Plan(scheme, cols, bands)
-            for v in p.out.values():
-                v.fill_(float("nan"))
-            p()
-            torch.cuda.synchronize()
-            for k in p.out:
-                assert bool(torch.isfinite(p.out[k]).all()), (name, k)
-                assert torch.equal(p.out[k], ref.out[k]), (name, k)
-    finally:
-        for k in keys:
-            lib.crt_hip_tune(k, 0)
-        lib.crt_hip_tune(0, 78 * 1024)
+    names = set()
+    for name, tune in paths.items():
+        p = batched.Plan(scheme, cols, bands, tune=tune)  # the overrides travel with the plan's calls: no global state to restore
+        for v in p.out.values():
+            v.fill_(float("nan"))
+        p()
+        names.add(p.last_kernel())
+        torch.cuda.synchronize()
+        for k in p.out:
+            assert bool(torch.isfinite(p.out[k]).all()), (name, k)
+            assert torch.equal(p.out[k], ref.out[k]), (name, k)
+    assert len(names) >= 2, names  # the settings really selected different kernels / configurations
 
 
 def test_plan_placement_auto():
-    """placement="auto" only changes WHERE the output arrays live (a few candidate allocations are timed, the fastest kept):
-    same results, a report of what was tried, and no effect on small problems or caller-provided buffers."""
+    """placement="auto" only changes WHERE the output arrays live (crt_hip_buffer_alloc_set: 512 MB physical chunks whose memory
+    classes are interleaved across the arrays of the set): same results, a report of the classes, no effect on small problems or
+    caller-provided buffers."""
     import torch
 
     from crt1d_amd import batched, synth
 
-    d = synth.make_columns(1600, 300, 60, seed=6)  # 4 x 230 MB of outputs: above the 256 MB threshold
+    d = synth.make_columns(2400, 300, 60, seed=6)  # 4 x 346 MB of outputs: above the 1 GB threshold of the set allocator
     cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
-    ref = batched.Plan("2s", cols, bands)
+    ref = batched.Plan("2s", cols, bands, placement="none")
+    assert ref.placement_report is None
     ref()
     p = batched.Plan("2s", cols, bands, placement="auto")
-    assert p.placement_report is not None and p.placement_report["candidates_timed"] >= 1  # stops at the first candidate in the fast mode
-    assert p.placement_report["best_ms"] <= p.placement_report["worst_ms"]
+    rep = p.placement_report
+    assert rep is not None and set(rep["classes"]) == set(ref.out)
+    assert all(isinstance(v, str) and len(v) == 1 and v in "XYZ?" for v in rep["classes"].values())  # one 512 MB chunk per array
     for v in p.out.values():
+        assert v.data_ptr() % (2 << 20) == 0
         v.fill_(float("nan"))
     p()
     torch.cuda.synchronize()
     for k in ref.out:
         assert torch.equal(p.out[k], ref.out[k]), k
+    st = batched.buffer_stats()
+    assert st["chunks_created"] >= 4 and st["probes"] >= 1 and 1 <= st["classes_seen"] <= 3
     small = batched.Plan("2s", batched.Columns.from_host(synth.make_columns(8, 64, 10)), batched.Bands.from_host(synth.make_columns(8, 64, 10)),
                          placement="auto")
     assert small.placement_report is None
@@ -392,30 +391,64 @@ def test_plan_placement_auto():
         batched.Plan("2s", cols, bands, placement="best")
 
 
-def test_device_buffer_roundtrip():
-    """crt_hip_buffer_alloc / _free behind batched.device_buffer: a normal torch tensor as far as the kernels and torch care."""
+def test_device_buffer_set_lifecycle():
+    """crt_hip_buffer_alloc_set / _free / _trim behind batched.device_buffers: normal torch tensors as far as the kernels and torch
+    care; the chunks of freed buffers are reused; no virtual range is ever mapped twice (the ROCm 7.2 re-mapping hazard,
+    csrc/buffers.hip), checked through the data: a live buffer keeps its contents while others are freed and re-allocated."""
     import gc
 
     import torch
 
-    from crt1d_amd import batched, synth
+    from crt1d_amd import _lib, batched, synth
 
     t = batched.device_buffer((3, 5, 7))
     assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.data_ptr() % (2 << 20) == 0
     t.fill_(2.5)
     assert float(t.sum()) == 2.5 * 105
-    d = synth.make_columns(2000, 128, 40, seed=2)  # 82 MB per array: above the 64 MB threshold of alloc_outputs(chunked=True)
+    assert batched.buffer_classes(t) in ("X", "Y", "Z", "?") and batched.buffer_classes(torch.empty(3, device="cuda")) is None
+    # a set of three arrays of 1.2 chunks each; the keeper holds a pattern across both of its chunks
+    n = (600 << 20) // 8
+    keep, b1, b2 = batched.device_buffers([(n,), (n,), (n,)])
+    keep.copy_(torch.arange(n, dtype=torch.float64, device="cuda"))
+    b1.fill_(1.0)
+    b2.fill_(2.0)
+    cls_keep = batched.buffer_classes(keep)
+    assert len(cls_keep) == 2
+    seen = {b1.data_ptr(), b2.data_ptr(), keep.data_ptr()}
+    for rnd in range(3):  # free and re-allocate around the keeper: new virtual ranges every time, chunks reused from the pool
+        del b1, b2
+        gc.collect()
+        b1, b2 = batched.device_buffers([(n,), (n,)])
+        assert b1.data_ptr() not in seen and b2.data_ptr() not in seen
+        seen |= {b1.data_ptr(), b2.data_ptr()}
+        b1.fill_(10.0 + rnd)
+        b2.fill_(20.0 + rnd)
+        torch.cuda.synchronize()
+        assert float(b1[0]) == 10.0 + rnd and float(b1[-1]) == 10.0 + rnd and float(b2[n // 2]) == 20.0 + rnd
+        assert bool((keep[:: 4097] == torch.arange(0, n, 4097, dtype=torch.float64, device="cuda")).all())
+    assert float(keep[n - 1]) == n - 1
+    st0 = batched.buffer_stats()
+    # the solve kernels run on such buffers like on any other memory
+    d = synth.make_columns(2000, 128, 40, seed=2)
     cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
-    out = batched.alloc_outputs("n79", 2000, 40, 128, "cuda", chunked=True)
+    shapes = [(2000, 40, 128)] * 4 + [(2000, 39, 128)] * 2
+    out = dict(zip(batched.OUT_KEYS["n79"], batched.device_buffers(shapes)))
     got = batched.Plan("n79", cols, bands, out=out)()
-    ref = batched.Plan("n79", cols, bands)()
+    ref = batched.Plan("n79", cols, bands, placement="none")()
     torch.cuda.synchronize()
     for k in ref:
         assert torch.equal(got[k], ref[k]), k
     f32 = batched.device_buffer((4, 4), dtype=torch.float32)
     assert f32.dtype == torch.float32
-    del t, out, got, f32
+    del t, out, got, f32, b1, b2, keep
     gc.collect()  # frees the buffers (crt_hip_buffer_free) without error
+    st1 = batched.buffer_stats()
+    assert st1["free_chunks"] >= 1
+    _lib.check(_lib.load().crt_hip_buffer_trim(), "crt_hip_buffer_trim")
+    st2 = batched.buffer_stats()
+    assert st2["free_chunks"] == 0 and st2["chunks_released"] > st0["chunks_released"]
+    with pytest.raises(ValueError):
+        _lib.check(_lib.load().crt_hip_buffer_free(12345), "crt_hip_buffer_free")
 
 
 def test_common_tau_functions_vs_reference():
@@ -447,31 +480,73 @@ def test_common_tau_functions_vs_reference():
 @pytest.mark.parametrize("uniform", [True, False])
 def test_zq_pa_fused_interpolation_equals_two_kernel_path(shape, uniform):
     """zq_pa in one kernel (the store waves interpolate from the computational grid to the caller's levels; no workspace scratch) must be
-    BITWISE the two-kernel path (grid solve into scratch + k_zqpa_interp; crt_hip_tune(10, 1) selects it): same expressions, and the
+    BITWISE the two-kernel path (grid solve into scratch + k_zqpa_interp; crt_options.tune[10] = 1 selects it): same expressions, and the
     rounds must hand every output level exactly the computational rows it needs (nz below, at and above the 100-layer grid)."""
     import torch
 
-    from crt1d_amd import _lib, batched, synth
+    from crt1d_amd import batched, synth
 
-    lib = _lib.load()
     d = synth.make_columns(*shape, seed=5, uniform_dlai=uniform)
     cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
-    try:
-        lib.crt_hip_tune(10, 1)
-        ref = batched.Plan("zq_pa", cols, bands)
-        ref()
-        torch.cuda.synchronize()
-    finally:
-        lib.crt_hip_tune(10, 0)
+    ref = batched.Plan("zq_pa", cols, bands, tune={10: 1})
+    ref()
+    torch.cuda.synchronize()
+    assert "two-kernel" in ref.last_kernel()
     for nsw in (0, 1, 4):
-        try:
-            lib.crt_hip_tune(11, nsw)
-            p = batched.Plan("zq_pa", cols, bands)
-            for v in p.out.values():
-                v.fill_(float("nan"))
-            p()
-            torch.cuda.synchronize()
-        finally:
-            lib.crt_hip_tune(11, 0)
+        p = batched.Plan("zq_pa", cols, bands, tune={11: nsw})
+        for v in p.out.values():
+            v.fill_(float("nan"))
+        p()
+        torch.cuda.synchronize()
         for k in ref.out:
             assert torch.equal(p.out[k], ref.out[k]), (k, nsw)
+
+
+@pytest.mark.parametrize("scheme", ["2s", "n79", "zq"])
+def test_g6_epilogue_kernels_vs_reference_golden(scheme):
+    """Rows a11 / a12 pinned on the reference itself: crt_hip_absorb_f64 and crt_hip_absorb_bandsum_f64 fed with the REFERENCE's
+    profiles (g1) against the reference's own `_calc_absorption` (model.py:573-647) outputs and the band sums formed with its
+    `_x_frac_in_bounds` weights (fixture g6, oracle/gen_golden.py)."""
+    import torch
+
+    from crt1d_amd import batched, spectra
+
+    g1, g6 = load_golden("g1_default"), load_golden("g6_absorption")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    cols = batched.Columns(t([float(g1["psi"])]), t(g1["lai"][None]), torch.tensor([4], dtype=torch.int32).cuda(), t([float(g1["x"])]))
+    bands = batched.Bands(t(g1["I_dr0_all"]), t(g1["I_df0_all"]), t(g1["leaf_r"]), t(g1["leaf_t"]), t(g1["soil_r"]))
+    sol = {k: t(g1[f"{scheme}__{k}"][None]) for k in ("I_dr", "I_df_d", "I_df_u")}
+    per = batched.absorb(cols, bands, sol)
+    scale = np.abs(g6[f"{scheme}__aI"]).max()
+    for k in batched.ABSORPTION_KEYS + ("laim", "f_slm"):
+        ref = g6[f"{scheme}__{k}"]
+        assert np.max(np.abs(per[k].cpu().numpy()[0] - ref)) <= 1e-13 * max(scale, np.abs(ref).max()), k
+    # weights: the host-side restatement of _x_frac_in_bounds is bit-exact against the reference's
+    names = [str(n) for n in g6["band_names"]]
+    W = np.stack([spectra.x_frac_in_bounds(g6["wle"], tuple(g6["band_bounds"][i])) for i in range(len(names))])
+    np.testing.assert_array_equal(W, g6["w_default"])
+    res = batched.absorb_bandsum(cols, bands, sol, t(W))
+    for k in ("aI", "aI_sl", "aI_sh"):
+        ref = g6[f"{scheme}__{k}__bandsum"]  # (ngroup, nz-1)
+        got = res[k].cpu().numpy()[0].T
+        assert np.max(np.abs(got - ref)) <= 1e-12 * np.abs(ref).max(), k
+
+
+def test_g6_epilogue_ragged_columns():
+    import torch
+
+    from crt1d_amd import batched
+
+    g4, g6 = load_golden("g4_ragged"), load_golden("g6_absorption")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    cols = batched.Columns(t(g4["psi"]), t(g4["lai"]), t(g4["g_kind"].astype(np.int32)), t(g4["g_param"]))
+    bands = batched.Bands(t(g4["I_dr0"]), t(g4["I_df0"]), t(g4["leaf_r"]), t(g4["leaf_t"]), t(g4["soil_r"]))
+    sol = {k: t(g4[f"2s__{k}"]) for k in ("I_dr", "I_df_d", "I_df_u")}
+    per = batched.absorb(cols, bands, sol)
+    for k in batched.ABSORPTION_KEYS + ("laim", "f_slm"):
+        ref = g6[f"ragged2s__{k}"]
+        assert np.max(np.abs(per[k].cpu().numpy() - ref)) <= 1e-13 * max(1.0, np.abs(ref).max()), k
+    res = batched.absorb_bandsum(cols, bands, sol, t(g6["w_synth"]))
+    for k in ("aI", "aI_sl", "aI_sh"):
+        ref = np.einsum("czb,gb->czg", g6[f"ragged2s__{k}"], g6["w_synth"])
+        assert np.max(np.abs(res[k].cpu().numpy() - ref)) <= 1e-12 * np.abs(ref).max(), k

@@ -200,3 +200,56 @@ def test_tau_d_vs_reference_common(oracle):
         np.testing.assert_allclose(oracle.tau_d(cols, g["lai"][None], method="9sky")[0], g[f"{name}__tau_d_9sky"], rtol=1e-13)
         # 'quad': the reference's QUADPACK result carries its own error (up to ~3e-8, vertical leaves at small LAI)
         np.testing.assert_allclose(oracle.tau_d(cols, g["lai"][None], method="quad")[0], g[f"{name}__tau_d_quad"], rtol=2e-7)
+
+
+# ---- G6: the reference's own `_calc_absorption` (model.py:573-647) and `_x_frac_in_bounds` (spectra.py:71-126) outputs,
+# produced by oracle/gen_golden.py from the reference's function definitions (SURVEY.md section 8(c) fixture G6)
+ABS_KEYS = ("aI", "aI_df", "aI_dr", "aI_sh", "aI_sl", "aI_df_sl", "aI_df_sh", "laim", "f_slm")
+
+
+@pytest.mark.parametrize("scheme", ["2s", "n79", "zq"])
+def test_g6_calc_absorption_default_case(oracle, scheme):
+    g1, g6 = load_golden("g1_default"), load_golden("g6_absorption")
+    cols = _cols(oracle, g1)
+    out = {k: g1[f"{scheme}__{k}"][None] for k in ("I_dr", "I_df_d", "I_df_u")}
+    ab = oracle.calc_absorption(cols, out, leaf_r=g1["leaf_r"], leaf_t=g1["leaf_t"])
+    scale = np.abs(g6[f"{scheme}__aI"]).max()
+    for k in ABS_KEYS:
+        ref = g6[f"{scheme}__{k}"]
+        assert np.max(np.abs(ab[k][0] - ref)) <= 1e-13 * max(scale, np.abs(ref).max()), k
+    # band weights and the band sums of diagnostics.py:81
+    names = [str(n) for n in g6["band_names"]]
+    for gi, n in enumerate(names):
+        w = oracle.x_frac_in_bounds(g6["wle"], tuple(g6["band_bounds"][gi]))
+        np.testing.assert_array_equal(w, g6["w_default"][gi])  # bit-exact: same IEEE operations
+        for k in ("aI", "aI_sl", "aI_sh"):
+            ref = g6[f"{scheme}__{k}__bandsum"][gi]
+            got = ab[k][0] @ w
+            assert np.max(np.abs(got - ref)) <= 1e-12 * max(np.abs(ref).max(), 1e-300), (n, k)
+
+
+def test_g6_calc_absorption_ragged_columns(oracle):
+    g4, g6 = load_golden("g4_ragged"), load_golden("g6_absorption")
+    cols = _cols(oracle, g4)
+    out = {k: g4[f"2s__{k}"] for k in ("I_dr", "I_df_d", "I_df_u")}
+    ab = oracle.calc_absorption(cols, out, leaf_r=g4["leaf_r"], leaf_t=g4["leaf_t"])
+    for k in ABS_KEYS:
+        ref = g6[f"ragged2s__{k}"]
+        assert np.max(np.abs(ab[k] - ref)) <= 1e-13 * max(1.0, np.abs(ref).max()), k
+    for gi in range(4):
+        np.testing.assert_array_equal(oracle.x_frac_in_bounds(g4["wle"], tuple(g6["band_bounds"][gi])), g6["w_synth"][gi])
+
+
+def test_ref_shaped_2s_equals_oracle(oracle):
+    """oracle/ref_shaped.solve_2s_loop (per-band Python loop: the CPU baseline's 'reference-shaped' leg) vs the vectorised
+    restatement and vs the reference's golden output."""
+    from oracle import ref_shaped
+
+    g = load_golden("g1_default")
+    cols = _cols(oracle, g)
+    res = ref_shaped.solve_2s_loop(psi=float(g["psi"]), lai=g["lai"], mla=float(g["mla"]), K_b=cols.K_b()[0], mu_bar=oracle.mu_bar(cols)[0],
+                                   I_dr0=g["I_dr0_all"], I_df0=g["I_df0_all"], leaf_r=g["leaf_r"], leaf_t=g["leaf_t"], soil_r=g["soil_r"])
+    vec = oracle.solve_2s(cols, **_kw(g, "2s"))
+    for k, v in res.items():
+        assert rel_profile_err(v, vec[k][0]) <= 1e-13, k
+        assert rel_profile_err(v, g[f"2s__{k}"]) <= 1e-11, k

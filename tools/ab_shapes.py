@@ -15,8 +15,7 @@ for scheme, ncol, nb, nz in [("2s", 30000, 107, 60), ("4s", 30000, 107, 60), ("g
     res = {k: [] for k in variants}
     for rnd in range(3):
         for name, tune in variants.items():
-            for k, v in tune.items():
-                lib.crt_hip_tune(k, v)
+            plan.set_tune(tune)
             flags = _lib.FLAG_SKIP_PRECOMPUTE
             plan(flags=flags); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -27,7 +26,5 @@ for scheme, ncol, nb, nz in [("2s", 30000, 107, 60), ("4s", 30000, 107, 60), ("g
             res[name].append(e0.elapsed_time(e1) / 5)
     gb = sum(v.numel() * 8 for v in plan.out.values()) / 1e9
     print(f"{scheme} {ncol}x{nb}x{nz} ({gb:.2f} GB): " + "  ".join(f"{k} {sorted(v)[len(v)//2]:.3f} ms = {gb / sorted(v)[len(v)//2]:.2f} TB/s" for k, v in res.items()), flush=True)
-    for k in (2, 3, 4):
-        lib.crt_hip_tune(k, 0)
     del plan, cols, bands
     torch.cuda.empty_cache()

@@ -44,8 +44,7 @@ for rnd in range(6):
         if tune is None:
             flags |= _lib.FLAG_DIRECT_STORES
         else:
-            for k, v in tune.items():
-                lib.crt_hip_tune(k, v)
+            plan.set_tune(tune)
         plan(flags=flags); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)

@@ -25,6 +25,6 @@ def per_launch(n=20):
     return sum(t) / n, t[0], t[n // 2]
 plan(); torch.cuda.synchronize()
 for name, tune in (("auto", {0: 78 * 1024, 1: 0}), ("forced T=8", {0: 160 * 1024, 1: 8}), ("forced T=4", {0: 40960, 1: 4}), ("auto again", {0: 78 * 1024, 1: 0})):
-    for k, v in tune.items(): lib.crt_hip_tune(k, v)
+    plan.set_tune(tune)
     plan(flags=F); torch.cuda.synchronize()
     print(f"{name:12s} back-to-back {b2b():.4f} ms | per-launch avg/min/med {per_launch()} | back-to-back {b2b():.4f}")

@@ -37,7 +37,7 @@ for rnd in range(5):
         if mt is None:
             flags |= _lib.FLAG_DIRECT_STORES
         else:
-            lib.crt_hip_tune(8, mt[0]); lib.crt_hip_tune(9, mt[1]); lib.crt_hip_tune(10, mt[2]); lib.crt_hip_tune(11, mt[3])
+            plan.set_tune({8: mt[0], 9: mt[1], 10: mt[2], 11: mt[3]})
         plan(flags=flags); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)

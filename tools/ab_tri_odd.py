@@ -15,7 +15,7 @@ for scheme, ncol, nb, nz in [("n79", 30000, 107, 60), ("zq", 30000, 107, 60), ("
     res = {k: [] for k in variants}
     for rnd in range(4):
         for name, (k10, k11) in variants.items():
-            lib.crt_hip_tune(10, k10); lib.crt_hip_tune(11, k11)
+            plan.set_tune({10: k10, 11: k11})
             flags = _lib.FLAG_SKIP_PRECOMPUTE
             plan(flags=flags); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -26,6 +26,5 @@ for scheme, ncol, nb, nz in [("n79", 30000, 107, 60), ("zq", 30000, 107, 60), ("
             res[name].append(e0.elapsed_time(e1) / 5)
     gb = sum(v.numel() * 8 for v in plan.out.values()) / 1e9
     print(f"{scheme} {ncol}x{nb}x{nz} ({gb:.2f} GB): " + "  ".join(f"{k} {sorted(v)[len(v)//2]:.3f} ms = {gb / sorted(v)[len(v)//2]:.2f} TB/s" for k, v in res.items()), flush=True)
-    lib.crt_hip_tune(10, 0); lib.crt_hip_tune(11, 0)
     del plan, cols, bands
     torch.cuda.empty_cache()

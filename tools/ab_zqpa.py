@@ -14,7 +14,7 @@ for ncol, nb, nz in [(10000, 300, 60), (6000, 300, 100), (30000, 128, 60)]:
     res = {k: [] for k in variants}
     for rnd in range(4):
         for name, (k10, k11) in variants.items():
-            lib.crt_hip_tune(10, k10); lib.crt_hip_tune(11, k11)
+            plan.set_tune({10: k10, 11: k11})
             plan(flags=_lib.FLAG_SKIP_PRECOMPUTE); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
@@ -22,7 +22,6 @@ for ncol, nb, nz in [(10000, 300, 60), (6000, 300, 100), (30000, 128, 60)]:
                 plan(st, flags=_lib.FLAG_SKIP_PRECOMPUTE)
             e1.record(st); torch.cuda.synchronize()
             res[name].append(e0.elapsed_time(e1) / 5)
-    lib.crt_hip_tune(10, 0); lib.crt_hip_tune(11, 0)
     gb = sum(v.numel() * 8 for v in plan.out.values()) / 1e9
     print(f"zq_pa {ncol}x{nb}x{nz} ({gb:.2f} GB): " + "  ".join(f"{k} {sorted(v)[len(v)//2]:.3f} ms" for k, v in res.items()), flush=True)
     del plan, cols, bands

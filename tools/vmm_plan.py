@@ -24,8 +24,8 @@ def timeit(out):
 
 keep = []
 for rnd in range(6):
-    a = batched.alloc_outputs(scheme, ncol, nz, nb, "cuda", chunked=False)
-    b = batched.alloc_outputs(scheme, ncol, nz, nb, "cuda", chunked=True)
+    a = batched.alloc_outputs(scheme, ncol, nz, nb, "cuda", placed=False)
+    b = batched.alloc_outputs(scheme, ncol, nz, nb, "cuda", placed=True)
     keep += [a, b]
     print(f"round {rnd}: torch.empty {timeit(a):.4f} ms   1 GB chunks {timeit(b):.4f} ms", flush=True)
 ref = base.out
