@@ -2,6 +2,9 @@
 // the absorption + band-integral epilogue kernel and the HBM bandwidth probes.
 #include <math.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "crt_internal.hpp"
 
 namespace crt {
@@ -9,10 +12,19 @@ namespace {
 
 // ------------------------------------------------------------------------------------------
 // Epilogue: model.py:573-647 (_calc_absorption) fused with diagnostics.py:39-108 (band sums).
-// One wave per (column, layer): lanes stride over the bands (coalesced 512-B row reads), accumulate
-// the weighted sums for up to MAXG band groups, then reduce across the wave with DPP shuffles.
+//
+// k_absorb_bandsum: ONE streaming pass over the three profiles.  Workgroup = column, thread = band (NBT bands per thread when
+// nb > 1024); the previous level's values stay in registers, so every profile byte is read exactly once (round 1 gave a
+// (column, layer) to each wave and read rows k and k+1: every row twice, 0.27 of the HBM roofline).  Per level only TWO
+// band sums per group are needed, because the sunlit/shaded split uses band-independent factors (as in the integrated
+// kernels, crt_internal.hpp):
+//     A_g(k) = sum_b w_g[b] aI(k, b),   D_g(k) = sum_b w_g[b] (1 - r - t)[b] I_dr(k+1, b)
+//     aI_dr = (1 - e^{-K_b dlai_k}) D,  aI_df = A - aI_dr,  aI_sl = aI_df f_sl(k) + aI_dr,  aI_sh = aI_df (1 - f_sl(k))
+// Wave sums by DPP (wave_sum_lane63), one LDS slot per wave and level; the levels are processed in chunks of BS_CH whose loads
+// are all issued before the arithmetic (24 rows in flight per thread), a double-buffered partial-sum area needs one LDS-only
+// barrier per chunk, and the first BS_CH * ngroup threads turn the partials of the previous chunk into outputs.
 constexpr int MAXG = 4;
-constexpr int EB = 256;
+constexpr int BS_CH = 8;
 
 struct EpiArgs {
   int ncol, nb, nz, ngroup;
@@ -34,85 +46,255 @@ struct EpiArgs {
   double* totals;
 };
 
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
-__global__ __launch_bounds__(EB) void k_absorb_bandsum(EpiArgs a) {
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void k_absorb_bandsum(EpiArgs a, int b0, int nbs, int accumulate) {
+  // bands [b0, b0 + nbs) of every row (nbs <= blockDim.x <= 1024; spectra wider than 1024 bands take several launches, the
+  // later ones adding to the outputs of the first)
+  extern __shared__ double lds[];
   const int c = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = EB >> 6;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
   const int nz = a.nz, nb = a.nb, ng = a.ngroup;
   const double psi = a.psi[c];
   const int kind = a.g_kind[c];
   const double G = (kind == CRT_G_TABLE) ? a.g_at_psi[c] : G_closed(kind, a.g_param ? a.g_param[c] : 0.0, cos(psi), sin(psi));
   const double Kb = G / cos(psi);
-  const double* lai = a.lai + (long long)c * nz;
-  const long long cb = (long long)c * nz * nb;
-  const double* lr = a.leaf_r + (long long)c * a.col_stride;
-  const double* lt = a.leaf_t + (long long)c * a.col_stride;
+  const double* __restrict__ lai = a.lai + (long long)c * nz;
+  const long long cb = (long long)c * nz * nb + b0;
+  const double* __restrict__ R = a.I_dr + cb;
+  const double* __restrict__ D = a.I_df_d + cb;
+  const double* __restrict__ U = a.I_df_u + cb;
+  // LDS: part[2][BS_CH][nwave][2][MAXG], ends[nwave][4][MAXG]
+  double* part = lds;
+  double* ends = lds + 2 * BS_CH * nwave * 2 * MAXG;
+  const int pstride = nwave * 2 * MAXG;  // doubles per level slot
 
-  for (int k = wave; k < nz - 1; k += nwave) {
-    const double dl = lai[k] - lai[k + 1];                    // model.py:248
-    const double fsl = exp(-Kb * ((lai[k] + lai[k + 1]) / 2)); // :601-602
-    const double absd = 1 - exp(-Kb * dl);                     // :619
-    const double* r0 = a.I_dr + cb + (long long)k * nb;
-    const double* d0 = a.I_df_d + cb + (long long)k * nb;
-    const double* u0 = a.I_df_u + cb + (long long)k * nb;
-    double sa[MAXG] = {0, 0, 0, 0}, ssl[MAXG] = {0, 0, 0, 0}, ssh[MAXG] = {0, 0, 0, 0};
-    for (int b = lane; b < nb; b += 64) {
-      const double idr1 = r0[nb + b];
-      const double av = idr1 - r0[b] + d0[nb + b] - d0[b] + u0[b] - u0[nb + b];  // :609
-      const double adr = idr1 * absd * (1 - (lr[b] + lt[b]));                    // :617-621
-      const double adf = av - adr;
-      const double asl = adf * fsl + adr;                                        // :631-633
-      const double ash = adf * (1 - fsl);
+  const bool act = tid < nbs;
+  const int bi = act ? tid : 0;
+  double w[MAXG], wa[MAXG];
+  {
+    const long long ib = (long long)c * a.col_stride + b0 + bi;
+    const double la = act ? 1 - (a.leaf_r[ib] + a.leaf_t[ib]) : 0.0;  // :584
 #pragma unroll
-      for (int g = 0; g < MAXG; ++g)
-        if (g < ng) {
-          const double w = a.band_w[(long long)g * nb + b];
-          sa[g] += w * av;
-          ssl[g] += w * asl;
-          ssh[g] += w * ash;
-        }
+    for (int g = 0; g < MAXG; ++g) {
+      w[g] = (g < ng && act) ? a.band_w[(long long)g * nb + b0 + bi] : 0.0;
+      wa[g] = w[g] * la;
     }
+  }
+  double r0 = R[bi], d0 = D[bi], u0 = U[bi];
+  // energy-balance terms at the ground (diagnostics.py:476-530): transmitted I_d[0], soil-reflected I_df_u[0]
+  if (a.totals) {
 #pragma unroll
     for (int g = 0; g < MAXG; ++g)
       if (g < ng) {
-        const double ta = wave_sum(sa[g]), tsl = wave_sum(ssl[g]), tsh = wave_sum(ssh[g]);
-        if (lane == 0) {
-          const long long o = ((long long)c * (nz - 1) + k) * ng + g;
-          a.aI[o] = ta;
-          a.aI_sl[o] = tsl;
-          a.aI_sh[o] = tsh;
+        const double t2 = wave_sum_lane63(w[g] * (r0 + d0)), t3 = wave_sum_lane63(w[g] * u0);
+        if (lane == 63) {
+          ends[(wave * 4 + 2) * MAXG + g] = t2;
+          ends[(wave * 4 + 3) * MAXG + g] = t3;
         }
       }
   }
-  if (wave == 0 && a.totals) {
-    // energy-balance terms of diagnostics.py:476-530: incoming, reflected, transmitted, soil-reflected
-    const long long top = cb + (long long)(nz - 1) * nb;
-    double s[MAXG][4] = {};
-    for (int b = lane; b < nb; b += 64) {
-#pragma unroll
-      for (int g = 0; g < MAXG; ++g)
-        if (g < ng) {
-          const double w = a.band_w[(long long)g * nb + b];
-          s[g][0] += w * (a.I_dr[top + b] + a.I_df_d[top + b]);
-          s[g][1] += w * a.I_df_u[top + b];
-          s[g][2] += w * (a.I_dr[cb + b] + a.I_df_d[cb + b]);
-          s[g][3] += w * a.I_df_u[cb + b];
+
+  auto finish_chunk = [&](int k0, int nlev, int buf) {  // first BS_CH * ng threads: partials of levels k0 .. k0+nlev-1 -> outputs
+    if (tid < BS_CH * ng) {
+      const int t = tid / ng, g = tid - t * ng;
+      if (t < nlev) {
+        const int k = k0 + t;
+        const double* p = part + (buf * BS_CH + t) * pstride;
+        double A = 0.0, Dg = 0.0;
+        for (int wv = 0; wv < nwave; ++wv) {
+          A += p[(wv * 2 + 0) * MAXG + g];
+          Dg += p[(wv * 2 + 1) * MAXG + g];
         }
+        const double dl = lai[k] - lai[k + 1];                      // model.py:248
+        const double fsl = exp(-Kb * ((lai[k] + lai[k + 1]) / 2));  // :601-602
+        const double adr = (1 - exp(-Kb * dl)) * Dg;                // :617-621
+        const double adf = A - adr;                                 // :628
+        const long long o = ((long long)c * (nz - 1) + k) * ng + g;
+        if (accumulate) {
+          a.aI[o] += A;
+          a.aI_sl[o] += adf * fsl + adr;
+          a.aI_sh[o] += adf * (1 - fsl);
+        } else {
+          a.aI[o] = A;
+          a.aI_sl[o] = adf * fsl + adr;                             // :631-633
+          a.aI_sh[o] = adf * (1 - fsl);
+        }
+      }
     }
+  };
+
+  int buf = 0, prev_k0 = -1, prev_n = 0;
+  for (int k0 = 0; k0 < nz - 1; k0 += BS_CH) {
+    const int nlev = min(BS_CH, nz - 1 - k0);
+    // all loads of the chunk first: rows k0+1 .. k0+nlev of the three profiles
+    double r1[BS_CH], d1[BS_CH], u1[BS_CH];
+#pragma unroll
+    for (int t = 0; t < BS_CH; ++t)
+      if (t < nlev) {
+        const long long row = (long long)(k0 + t + 1) * nb + bi;
+        r1[t] = __builtin_nontemporal_load(R + row);
+        d1[t] = __builtin_nontemporal_load(D + row);
+        u1[t] = __builtin_nontemporal_load(U + row);
+      }
+    if (prev_k0 >= 0) finish_chunk(prev_k0, prev_n, buf ^ 1);  // the previous chunk's outputs while this chunk's loads are in flight
+#pragma unroll
+    for (int t = 0; t < BS_CH; ++t)
+      if (t < nlev) {
+        const double av = r1[t] - r0 + d1[t] - d0 + u0 - u1[t];  // :609
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g)
+          if (g < ng) {
+            const double ta = wave_sum_lane63(w[g] * av), td = wave_sum_lane63(wa[g] * r1[t]);
+            if (lane == 63) {
+              double* p = part + (buf * BS_CH + t) * pstride;
+              p[(wave * 2 + 0) * MAXG + g] = ta;
+              p[(wave * 2 + 1) * MAXG + g] = td;
+            }
+          }
+        r0 = r1[t];
+        d0 = d1[t];
+        u0 = u1[t];
+      }
+    lds_barrier();  // chunk complete (and every thread is past its reads of the other buffer)
+    prev_k0 = k0;
+    prev_n = nlev;
+    buf ^= 1;
+  }
+  // canopy top: incoming I_d[top], reflected I_df_u[top] (r0, d0, u0 now hold level nz-1)
+  if (a.totals) {
 #pragma unroll
     for (int g = 0; g < MAXG; ++g)
       if (g < ng) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const double t = wave_sum(s[g][i]);
-          if (lane == 0) a.totals[((long long)c * ng + g) * 4 + i] = t;
+        const double t0 = wave_sum_lane63(w[g] * (r0 + d0)), t1 = wave_sum_lane63(w[g] * u0);
+        if (lane == 63) {
+          ends[(wave * 4 + 0) * MAXG + g] = t0;
+          ends[(wave * 4 + 1) * MAXG + g] = t1;
         }
       }
+  }
+  if (prev_k0 >= 0) finish_chunk(prev_k0, prev_n, buf ^ 1);
+  if (a.totals) {
+    lds_barrier();
+    if (tid < ng * 4) {
+      const int g = tid >> 2, q = tid & 3;
+      double t = 0.0;
+      for (int wv = 0; wv < nwave; ++wv) t += ends[(wv * 4 + q) * MAXG + g];
+      double* o = a.totals + ((long long)c * ng + g) * 4 + q;
+      *o = accumulate ? *o + t : t;
+    }
+  }
+}
+
+// k_absorb_bandsum_w: the same pass with ONE WAVE PER COLUMN (nb <= 512): lane l owns bands l, l + 64, ... (NBT of them), so
+// the cross-band reduction of a level costs one set of lane exchanges per COLUMN instead of one per wave of a multi-wave
+// workgroup -- the kernel above spends most of its instructions there (2 ngroup reductions x 18 VALU instructions x 5 waves per
+// level at nb = 300: VALU-bound at 2.1 TB/s, measured) -- and the exchanges themselves reduce FOUR values at a time (wave_sum4,
+// crt_internal.hpp: 5 instructions per value instead of 18).  No barriers, no cross-wave traffic: the waves of a workgroup are
+// independent columns.  The raw band sums A_g(k), D_g(k) go to LDS; at the end the lanes turn them into the level outputs
+// (level factors f_sl(k), 1 - e^{-K_b dlai_k} evaluated there, lanes over levels) and write them coalesced.
+template <int NBT, int CH, int NGT>
+__global__ __launch_bounds__(256) void k_absorb_bandsum_w(EpiArgs a, int wpb, int per_wave) {
+  extern __shared__ double lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // wave-uniform column index in a scalar register: the profile pointers below then are scalar bases, and every load is
+  // "scalar base + one 32-bit lane offset" shared by the three arrays (15 offset registers instead of 90 address registers)
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
+  if (c >= a.ncol) return;  // (no workgroup barrier anywhere in this kernel)
+  const int nz = a.nz, nb = a.nb, ng = a.ngroup, nl = nz - 1;
+  double* raw = lds + (size_t)wave * per_wave;  // [nl][NGT][2]: A_g(k), D_g(k)
+  double* ends = raw + 2 * NGT * nl;            // [2][NGT][2]: ground (I_d, I_df_u), top (I_d, I_df_u)
+  const long long cb = (long long)c * nz * nb;
+  const double* __restrict__ R = a.I_dr + cb;
+  const double* __restrict__ D = a.I_df_d + cb;
+  const double* __restrict__ U = a.I_df_u + cb;
+  int bi[NBT];
+  double w[NBT][NGT], la[NBT], r0[NBT], d0[NBT], u0[NBT];  // NGT >= ngroup: weight registers for the groups in use only
+#pragma unroll
+  for (int i = 0; i < NBT; ++i) {
+    const int b = lane + 64 * i;
+    const bool act = b < nb;
+    bi[i] = act ? b : 0;
+    const long long ib = (long long)c * a.col_stride + bi[i];
+    la[i] = act ? 1 - (a.leaf_r[ib] + a.leaf_t[ib]) : 0.0;  // :584
+#pragma unroll
+    for (int g = 0; g < NGT; ++g) w[i][g] = (g < ng && act) ? a.band_w[(long long)g * nb + bi[i]] : 0.0;
+    r0[i] = R[bi[i]];
+    d0[i] = D[bi[i]];
+    u0[i] = U[bi[i]];
+  }
+  auto end_terms = [&](double* dst) {  // sum_b w (I_dr + I_df_d), sum_b w I_df_u of the level held in r0, d0, u0
+    double v[2 * NGT];
+#pragma unroll
+    for (int g = 0; g < NGT; ++g) {
+      v[2 * g] = v[2 * g + 1] = 0.0;
+#pragma unroll
+      for (int i = 0; i < NBT; ++i) {
+        v[2 * g] += w[i][g] * (r0[i] + d0[i]);
+        v[2 * g + 1] += w[i][g] * u0[i];
+      }
+    }
+    wave_sum_store(v, dst, 2 * NGT, lane);
+  };
+  if (a.totals) end_terms(ends);  // ground: transmitted I_d[0], soil-reflected I_df_u[0]  (diagnostics.py:476-530)
+  for (int k0 = 0; k0 < nl; k0 += CH) {
+    const int nlev = min(CH, nl - k0);
+    double r1[CH][NBT], d1[CH][NBT], u1[CH][NBT];
+#pragma unroll
+    for (int t = 0; t < CH; ++t)
+      if (t < nlev) {
+        const unsigned row = (unsigned)(k0 + t + 1) * (unsigned)nb;  // nz * nb < 2^31 (checked by the launcher)
+#pragma unroll
+        for (int i = 0; i < NBT; ++i) {
+          const unsigned off = row + (unsigned)bi[i];
+          r1[t][i] = __builtin_nontemporal_load(R + off);
+          d1[t][i] = __builtin_nontemporal_load(D + off);
+          u1[t][i] = __builtin_nontemporal_load(U + off);
+        }
+      }
+    double v[CH * NGT * 2];  // [t][g][A, D]
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+#pragma unroll
+      for (int g = 0; g < NGT; ++g) v[(t * NGT + g) * 2] = v[(t * NGT + g) * 2 + 1] = 0.0;
+      if (t < nlev) {
+#pragma unroll
+        for (int i = 0; i < NBT; ++i) {
+          const double av = r1[t][i] - r0[i] + d1[t][i] - d0[i] + u0[i] - u1[t][i];  // :609
+          const double ar = la[i] * r1[t][i];                                         // :617-621 without the level factor
+#pragma unroll
+          for (int g = 0; g < NGT; ++g) {
+            v[(t * NGT + g) * 2] += w[i][g] * av;
+            v[(t * NGT + g) * 2 + 1] += w[i][g] * ar;
+          }
+          r0[i] = r1[t][i];
+          d0[i] = d1[t][i];
+          u0[i] = u1[t][i];
+        }
+      }
+    }
+    wave_sum_store(v, raw + (size_t)k0 * NGT * 2, nlev * NGT * 2, lane);
+  }
+  if (a.totals) end_terms(ends + 2 * NGT);  // canopy top: incoming I_d[top], reflected I_df_u[top]
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave: LDS operations complete in order; make the sums visible to all lanes
+  const double psi = a.psi[c];
+  const int kind = a.g_kind[c];
+  const double G = (kind == CRT_G_TABLE) ? a.g_at_psi[c] : G_closed(kind, a.g_param ? a.g_param[c] : 0.0, cos(psi), sin(psi));
+  const double Kb = G / cos(psi);
+  const double* __restrict__ lai = a.lai + (long long)c * nz;
+  const long long ob = (long long)c * nl * ng;
+  for (int i = lane; i < nl * ng; i += 64) {
+    const int k = i / ng, g = i - k * ng;
+    const double A = raw[(k * NGT + g) * 2], Dg = raw[(k * NGT + g) * 2 + 1];
+    const double fsl = exp(-Kb * ((lai[k] + lai[k + 1]) / 2));  // model.py:601-602
+    const double adr = (1 - exp(-Kb * (lai[k] - lai[k + 1]))) * Dg;  // :617-621
+    const double adf = A - adr;                                  // :628
+    a.aI[ob + i] = A;
+    a.aI_sl[ob + i] = adf * fsl + adr;                           // :631-633
+    a.aI_sh[ob + i] = adf * (1 - fsl);
+  }
+  if (a.totals && lane < 4 * ng) {  // incoming, reflected, transmitted, soil-reflected
+    const int g = lane >> 2, q = lane & 3;
+    a.totals[((long long)c * ng + g) * 4 + q] = ends[(q < 2 ? 2 * NGT : 0) + 2 * g + (q & 1)];
   }
 }
 
@@ -395,7 +577,44 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
   a.aI_sl = aI_sl;
   a.aI_sh = aI_sh;
   a.totals = totals;
-  hipLaunchKernelGGL(k_absorb_bandsum, dim3(a.ncol), dim3(EB), 0, static_cast<hipStream_t>(stream), a);
+  if (a.nb <= 512 && (long long)a.nz * a.nb < (1ll << 31)) {  // one wave per column
+    const int nl = a.nz - 1;
+    const int ngt = a.ngroup == 1 ? 1 : a.ngroup <= 3 ? 3 : 4;
+    const int per_wave = 2 * ngt * nl + 4 * ngt;
+    int wpb = 4;
+    while (wpb > 1 && (size_t)wpb * per_wave * sizeof(double) > 60 * 1024) wpb >>= 1;
+    const size_t shw = (size_t)wpb * per_wave * sizeof(double);
+    if (shw <= 64 * 1024) {
+      const int nbt = (a.nb + 63) / 64;
+      const dim3 grid((a.ncol + wpb - 1) / wpb), block(64 * wpb);
+      hipStream_t sw = static_cast<hipStream_t>(stream);
+      auto launch = [&](auto ngt) {
+        constexpr int NGT = decltype(ngt)::value;
+        switch (nbt) {
+          case 1: hipLaunchKernelGGL((k_absorb_bandsum_w<1, 4, NGT>), grid, block, shw, sw, a, wpb, per_wave); break;
+          case 2: hipLaunchKernelGGL((k_absorb_bandsum_w<2, 4, NGT>), grid, block, shw, sw, a, wpb, per_wave); break;
+          case 3: hipLaunchKernelGGL((k_absorb_bandsum_w<3, 4, NGT>), grid, block, shw, sw, a, wpb, per_wave); break;
+          case 4: hipLaunchKernelGGL((k_absorb_bandsum_w<4, 2, NGT>), grid, block, shw, sw, a, wpb, per_wave); break;
+          case 5: hipLaunchKernelGGL((k_absorb_bandsum_w<5, 2, NGT>), grid, block, shw, sw, a, wpb, per_wave); break;
+          case 6: hipLaunchKernelGGL((k_absorb_bandsum_w<6, 2, NGT>), grid, block, shw, sw, a, wpb, per_wave); break;
+          default: hipLaunchKernelGGL((k_absorb_bandsum_w<8, 2, NGT>), grid, block, shw, sw, a, wpb, per_wave); break;
+        }
+      };
+      if (a.ngroup == 1) launch(std::integral_constant<int, 1>{});
+      else if (a.ngroup <= 3) launch(std::integral_constant<int, 3>{});
+      else launch(std::integral_constant<int, 4>{});
+      return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+    }
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int b0 = 0; b0 < a.nb; b0 += 1024) {  // one launch per 1024 bands (the usual case: one)
+    const int nbs = std::min(1024, a.nb - b0);
+    const int nthr = ((nbs + 63) / 64) * 64;
+    const size_t sh = ((size_t)2 * BS_CH * (nthr / 64) * 2 * MAXG + (size_t)(nthr / 64) * 4 * MAXG) * sizeof(double);
+    if (nthr <= 256) hipLaunchKernelGGL((k_absorb_bandsum<256>), dim3(a.ncol), dim3(nthr), sh, s, a, b0, nbs, b0 > 0);
+    else if (nthr <= 512) hipLaunchKernelGGL((k_absorb_bandsum<512>), dim3(a.ncol), dim3(nthr), sh, s, a, b0, nbs, b0 > 0);
+    else hipLaunchKernelGGL((k_absorb_bandsum<1024>), dim3(a.ncol), dim3(nthr), sh, s, a, b0, nbs, b0 > 0);
+  }
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 

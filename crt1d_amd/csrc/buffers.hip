@@ -214,73 +214,37 @@ int crt_hip_buffer_alloc_set(int32_t n, const size_t* bytes, void** ptrs) {
   auto balanced = [&]() {
     if (have.size() < need) return false;
     if (need < 2) return true;
-    size_t cnt[NCLS + 1];
-    size_t most = 0;
-    for (int c = 0; c <= NCLS; ++c) {
-      cnt[c] = count(c);
-      if (c < NCLS) most = std::max(most, cnt[c]);
-    }
-    // the classes other than the largest one can supply 40 % of the selection
-    return have.size() - most >= (need * 2 + 4) / 5;
-  };
-  // Gathering: first `need` chunks, whatever they are.  If they cannot be balanced (a process often starts inside a run of
-  // 10-35 GB of one class), hunt for another class: keep what we hold, put unmapped SPACER allocations of 1, 2, 4, 8 GB in
-  // front of the driver's allocation cursor and sample one chunk behind each, until the other classes can supply 40 % of
-  // the request or the exploration budget (memory held at one time) is spent.  Spacers and surplus chunks are released
-  // before returning; the whole hunt costs a few ms per sample.
-  size_t free0 = 0, tot0 = 0;
-  if (hipMemGetInfo(&free0, &tot0) != hipSuccess) free0 = need * CHUNK + (22ull << 30);
-  const size_t budget = std::min<size_t>(free0 > (6ull << 30) ? free0 - (6ull << 30) : 0, need * CHUNK + (112ull << 30));
-  std::vector<hipMemGenericAllocationHandle_t> spacers;
-  size_t spacer_bytes = 0, next_spacer = 1ull << 30;
-  int run = 0;
-  bool oom = false;
-  auto majority = [&]() {
-    int best = 0;
-    size_t nbest = 0;
+    size_t most = 0, classified = 0;
     for (int c = 0; c < NCLS; ++c) {
       const size_t k = count(c);
-      if (k > nbest) { nbest = k; best = c; }
+      classified += k;
+      most = std::max(most, k);
     }
-    return best;
+    // the classes other than the largest one can supply 40 % of the selection (ambiguous chunks count for nothing)
+    return classified - most >= (need * 2 + 4) / 5;
   };
+  // Gathering: first `need` chunks, whatever they are.  If they cannot be balanced (a process often starts inside a run of
+  // 10-35 GB of one class), keep allocating and classifying chunks -- holding everything, so that the driver has to move on to
+  // other memory -- until the other classes can supply 40 % of the request or the exploration budget (memory held at one time)
+  // is spent; ~1.7 ms per chunk (create + map + probe), i.e. ~0.15 s for 40 GB.  (Large unmapped "spacer" allocations do not
+  // move the driver's cursor for 512 MB requests -- they are served from other free blocks -- and cost 0.3 s each: tried, dropped.)
+  // Surplus chunks are released before returning, rarest classes kept.
+  size_t free0 = 0, tot0 = 0;
+  if (hipMemGetInfo(&free0, &tot0) != hipSuccess) free0 = need * CHUNK + (22ull << 30);
+  const size_t budget = std::min<size_t>(free0 > (6ull << 30) ? free0 - (6ull << 30) : 0, need * CHUNK + (96ull << 30));
+  bool oom = false;
   while (!balanced()) {
-    const size_t held = have.size() * CHUNK + spacer_bytes;
-    if (held + CHUNK > budget) {
-      if (have.size() < need) oom = true;
+    if ((have.size() + 1) * CHUNK > budget) {
+      oom = have.size() < need;
       break;
-    }
-    if (have.size() >= need && run >= 2) {  // inside a run of the majority class: jump ahead
-      const size_t sp = std::min(next_spacer, budget - held - CHUNK);
-      if (sp >= (512ull << 20)) {
-        hipMemAllocationProp prop = dev_prop(dev);
-        hipMemGenericAllocationHandle_t h;
-        if (hipMemCreate(&h, sp, &prop, 0) == hipSuccess) {
-          spacers.push_back(h);
-          spacer_bytes += sp;
-          next_spacer = std::min<size_t>(next_spacer * 2, 8ull << 30);
-        } else {
-          (void)hipGetLastError();
-          break;
-        }
-      }
     }
     Chunk c;
     if (!new_chunk(p, dev, c)) {
       oom = have.size() < need;
       break;
     }
-    const int nref_before = p.nref;
-    if (classify(p, c)) {
-      have.push_back(c);
-      if (c.cls == majority()) ++run;
-      else { run = 0; next_spacer = 1ull << 30; }
-    } else if (p.nref > nref_before) {  // founded a new class (and became its reference): we are in another run now
-      run = 0;
-      next_spacer = 1ull << 30;
-    }
+    if (classify(p, c)) have.push_back(c);
   }
-  for (auto h : spacers) (void)hipMemRelease(h);
   if (have.size() < need) {
     p.free_chunks.swap(have);
     return oom ? CRT_ERR_WORKSPACE : CRT_ERR_LAUNCH;
@@ -321,9 +285,15 @@ int crt_hip_buffer_alloc_set(int32_t n, const size_t* bytes, void** ptrs) {
       per[a].push_back(take(best));
     }
   // ---- unselected chunks: newly gathered surplus goes back to the driver (keep a few for the next small request)
-  while (have.size() > 4) {
-    release_chunk(p, have.back());
-    have.pop_back();
+  {  // (the spares kept are the rarest classes: they are what the next request will be short of)
+    std::stable_sort(have.begin(), have.end(), [&](const Chunk& x, const Chunk& y) {
+      const size_t cx = x.cls < NCLS ? avail[x.cls] : (size_t)-1, cy = y.cls < NCLS ? avail[y.cls] : (size_t)-1;
+      return cx < cy;
+    });
+    while (have.size() > 6) {
+      release_chunk(p, have.back());
+      have.pop_back();
+    }
   }
   p.free_chunks.swap(have);
   // ---- map every array into a fresh virtual range (second mapping of its chunks)

@@ -277,6 +277,37 @@ __device__ inline double wave_sum_lane63(double v) {
   v = dpp_add_rows<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
   return v;
 }
+// FOUR per-lane values -> their four wave totals in ONE register: the lanes of DPP row 0 end up with sum(a), row 1 with sum(c),
+// row 2 with sum(b), row 3 with sum(d).  v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves / odd-even rows between
+// two registers, so each swap + add halves the number of registers while summing across the halves; one row_sum16 finishes all
+// four at once: 2 x 3 + 3 + 12 = 21 VALU instructions for four totals, against 4 x 18 for four wave_sum_lane63.
+__device__ inline double swap_add32(double x, double y) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ inline double swap_add16(double x, double y) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ inline double wave_sum4(double a, double b, double c, double d) {
+  return row_sum16(swap_add16(swap_add32(a, b), swap_add32(c, d)));
+}
+// index (0..3 = a, b, c, d) of the value whose total a lane of DPP row `row` holds after wave_sum4
+__device__ inline int wave_sum4_slot(int row) { return ((row & 1) << 1) | (row >> 1); }
+// wave totals of v[0..N) written to dst[0..nvalid) (LDS or global) by the first lane of each row, four values per pass
+template <int N>
+__device__ inline void wave_sum_store(const double (&v)[N], double* dst, int nvalid, int lane) {
+  const int slot = wave_sum4_slot(lane >> 4);
+#pragma unroll
+  for (int j = 0; j < (N + 3) / 4; ++j) {
+    const double z = wave_sum4(v[4 * j], 4 * j + 1 < N ? v[4 * j + 1] : 0.0, 4 * j + 2 < N ? v[4 * j + 2] : 0.0, 4 * j + 3 < N ? v[4 * j + 3] : 0.0);
+    const int idx = 4 * j + slot;
+    if ((lane & 15) == 0 && idx < nvalid) dst[idx] = z;
+  }
+}
+
 __device__ inline double wave_sum_all(double v) {  // sum over the 64 lanes (used once per column only)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
