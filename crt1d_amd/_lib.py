@@ -57,7 +57,7 @@ class CrtBands(ctypes.Structure):
     ]
 
 
-NTUNE = 12
+NTUNE = 16
 
 
 class CrtOptions(ctypes.Structure):

@@ -83,7 +83,7 @@ struct SolveArgs {
   // kernel-selection overrides of THIS call (crt_options.tune; 0 = automatic): [0] LDS bytes a closed-form tile may take,
   // [1] force T of k_tile, [2] flags (bit0 __syncthreads barriers, bit1 generic flush, bit2 no pipeline, bit3 no generic-flush
   // pipeline), [3] store waves of k_pipe, [4] T of k_pipe; [8] M, [9] T, [10] kernel family, [11] store waves of the tridiagonal
-  // kernels (tri_tile_impl.hpp)
+  // kernels (tri_tile_impl.hpp); [12] smallest nb that takes the tile / pipeline kernels (0 = default)
   int tune[CRT_NTUNE];
 };
 

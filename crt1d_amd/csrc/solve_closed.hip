@@ -743,6 +743,7 @@ constexpr int MAX_DIRECT_LDS = 64 * 1024;
 //   T=2 (not line aligned) 1.66 ms | T=4, 4 WG/CU 1.20 ms | T=8, 2 WG/CU 1.03 ms | T=12, 1 WG/CU 1.25 ms
 // -> take the longest line-aligned run that still leaves two workgroups resident per CU (160 KB LDS).
 constexpr int DEFAULT_TILE_LDS = 78 * 1024;
+constexpr int MIN_TILE_NB = 64;
 
 int gcd(int x, int y) { return y ? gcd(y, x % y) : x; }
 
@@ -753,7 +754,8 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
   int g_tune[8];  // this call's overrides (crt_options.tune); [0] = 0 means the default LDS budget
   for (int i = 0; i < 8; ++i) g_tune[i] = a.tune[i];
   if (g_tune[0] <= 0) g_tune[0] = DEFAULT_TILE_LDS;
-  if (nb < 64 || nb > 1024) return CRT_OK;
+  const int min_nb = a.tune[12] > 0 ? a.tune[12] : MIN_TILE_NB;
+  if (nb < min_nb || nb > 1024) return CRT_OK;
   const int CB = nb <= 256 ? 256 / nb : 1;
   const int nthr = CB > 1 ? 256 : ((nb + 63) / 64) * 64;
   const int line = 128 / (int)sizeof(TIO);  // elements per 128-B line

@@ -722,6 +722,7 @@ template <class S, typename TIO>
 int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 64) {
   done = false;
   const int* g_tri_tune = a.tune + 8;  // this call's overrides (crt_options.tune[8..11])
+  if (a.tune[12] > 0) min_nb = a.tune[12];
   if (a.nb < min_nb || a.nb > 1024) return CRT_OK;  // narrow spectra: the per-wave kernels fill their lanes better
   const int nthr = ((a.nb + 63) / 64) * 64;
   const int K = S::rows(a.nz);

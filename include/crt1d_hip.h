@@ -109,7 +109,7 @@ typedef struct crt_bands {
 #define CRT_FLAG_DIRECT_STORES 4   /* measurement aid: use the direct-store solve kernel even where the LDS-tiled,
                                       line-aligned one applies (same results, different store pattern) */
 
-#define CRT_NTUNE 12
+#define CRT_NTUNE 16
 typedef struct crt_options {
   double mu_s;            /* 4s: cosine of the dividing angle, default 0.501 (_solve_4s.py:9) */
   int32_t tau_d_method;   /* n79: crt_tau_d_method, default CRT_TAU_D_QUAD (_solve_n79.py:19) */

@@ -46,8 +46,14 @@ def rel_profile_err(got, ref):
     return float(np.max(np.abs(got - ref) / scale))
 
 
-def rel_elem_err(got, ref, floor=0.0):
+def rel_elem_err(got, ref, floor_frac=1e-9):
+    """ELEMENTWISE relative error, max over everything of |got - ref| / max(|ref|, floor), the form north_star words
+    ("within 1e-6 relative").  floor = floor_frac x (max |ref| over the level axis of that (column, band)): an element more than
+    nine orders of magnitude below its own profile's maximum is compared against that floor instead of against itself (the
+    upward flux of bl is identically zero; tails of deep canopies underflow towards it)."""
     got, ref = np.asarray(got), np.asarray(ref)
-    den = np.maximum(np.abs(ref), floor)
-    m = den > 0
-    return float(np.max(np.abs(got - ref)[m] / den[m])) if m.any() else 0.0
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    ax = got.ndim - 2
+    scale = np.abs(ref).max(axis=ax, keepdims=True)
+    den = np.maximum(np.abs(ref), floor_frac * np.where(scale == 0, 1.0, scale))
+    return float(np.max(np.abs(got - ref) / den))
