@@ -743,7 +743,10 @@ constexpr int MAX_DIRECT_LDS = 64 * 1024;
 //   T=2 (not line aligned) 1.66 ms | T=4, 4 WG/CU 1.20 ms | T=8, 2 WG/CU 1.03 ms | T=12, 1 WG/CU 1.25 ms
 // -> take the longest line-aligned run that still leaves two workgroups resident per CU (160 KB LDS).
 constexpr int DEFAULT_TILE_LDS = 78 * 1024;
-constexpr int MIN_TILE_NB = 64;
+// Narrow spectra (the 36-38-band shards of an 8-rank band partition): one compute wave + store waves per column beats the
+// direct-store kernel 1.3-1.6x down to 16 bands (tools/ab_narrow.py, 2e5 x 38 x 60: k_direct 4.36 ms, k_pipe 2.67-2.74 ms;
+// 4s: 2.25 -> 1.71 ms with one store wave); below 16 bands the direct kernel keeps its lanes fuller.
+constexpr int MIN_TILE_NB = 16;
 
 int gcd(int x, int y) { return y ? gcd(y, x % y) : x; }
 
@@ -793,7 +796,7 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
     const bool fused = pfused;  // (shadows k_tile's flag inside this block)
     const int pcomp = ((nb + 63) / 64) * 64;
     const size_t plevel = (size_t)S::NARR * nb * sizeof(TIO);
-    int nsw = g_tune[3] > 0 ? g_tune[3] : (pcomp <= 128 ? 2 : 3);
+    int nsw = g_tune[3] > 0 ? g_tune[3] : (pcomp <= 64 && S::HEAVY_INIT ? 1 : pcomp <= 128 ? 2 : 3);
     if (pcomp + 64 * nsw > 1024) nsw = (1024 - pcomp) / 64;
     // Two tile buffers of up to 8 levels, line-aligned runs when they fit, at least two workgroups per CU -- and about four
     // for a scheme with a heavy per-band set-up when the spectrum is narrow enough to allow it.  Measured (tools/ab_shapes.py,

@@ -718,8 +718,11 @@ int launch_pipe(const SolveArgs& a, hipStream_t s, int M, int T, int nsw, bool r
   return CRT_ERR_UNSUPPORTED;
 }
 
+// min_nb: narrow spectra (the 36-38-band shards of an 8-rank band partition) run one compute wave + ONE store wave per column:
+// tools/ab_narrow.py, zq 1e5 x 38 x 100: k_tri_wave 7.54 ms (2.8 TB/s), pipeline with 3 / 2 / 1 store waves 4.5 / 4.2 / 3.74 ms
+// (5.7 TB/s); n79 1e5 x 38 x 60: 4.38 -> 2.13 ms.  Below 16 bands the per-wave kernel keeps its lanes fuller.
 template <class S, typename TIO>
-int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 64) {
+int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 16) {
   done = false;
   const int* g_tri_tune = a.tune + 8;  // this call's overrides (crt_options.tune[8..11])
   if (a.tune[12] > 0) min_nb = a.tune[12];
@@ -759,7 +762,7 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 64
   // zq 2.35 -> 2.29, zq nz=100 3.00 -> 2.22; nb=255 n79 1.60 -> 2.39, zq 2.25 -> 2.86), so only zq on narrow spectra takes it
   // (tune key 10 = 4 forces it for any scheme and nb).
   if (!fused && g_tri_tune[2] != 1 && g_tri_tune[0] == 0 && ((nthr <= 128 && S::NOUT == 7) || g_tri_tune[2] == 4)) {
-    const int nsw = g_tri_tune[3] > 0 ? g_tri_tune[3] : 2;
+    const int nsw = g_tri_tune[3] > 0 ? g_tri_tune[3] : (nthr == 64 ? 1 : 2);
     int st = launch_pipe_generic<S, TIO, 12, 4>(a, s, nsw);
     if (st == CRT_ERR_UNSUPPORTED) st = launch_pipe_generic<S, TIO, 16, 4>(a, s, nsw);
     if (st != CRT_ERR_UNSUPPORTED) {
@@ -780,7 +783,7 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 64
       // tune key 10: 0 = automatic, 1 = no pipeline, 2 = double-buffer pipeline only, 3 = register-staged only
       const bool try_rs = g_tri_tune[2] != 2, try_db = g_tri_tune[2] != 3;
       // register-staged: 5 compute + 3 store waves = 8 waves per workgroup, two workgroups fill the 16 wave slots of a CU at <= 128 VGPRs
-      const int nsw_rs = g_tri_tune[3] > 0 ? nsw : min(nsw, 3);
+      const int nsw_rs = g_tri_tune[3] > 0 ? nsw : (nthr == 64 ? 1 : min(nsw, 3));
       if (g_tri_tune[0] > 0) {
         if (try_rs) st = launch_pipe<S, TIO>(a, s, M, T, nsw_rs, true);
         if (st == CRT_ERR_UNSUPPORTED && try_db) st = launch_pipe<S, TIO>(a, s, M, T, nsw, false);

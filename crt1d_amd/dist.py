@@ -6,7 +6,7 @@ The (column x band) solves are independent units; nothing 
 * ``partition="column"`` (preferred): rank r owns a contiguous block of columns, all bands.  Zero
   communication -- integrated quantities are per column and stay on the owning rank.
 * ``partition="band"``: rank r owns a contiguous block of bands of ALL columns (300 bands on 8 ranks ->
-  38,38,38,38,37,37,37,37).  The per-column precompute is replicated.  The only cross-band coupling is the
+  38 x 6 + 36 x 2: dealt in pairs, :func:`band_block_range`).  The per-column precompute is replicated.  The only cross-band coupling is the
   spectral integral ``sum_wl w X`` (``crt1d/diagnostics.py:81``), so each rank forms partial band sums of the
   layer absorption and of the energy-balance terms and ONE all-reduce(sum) of one packed fp64 buffer per column tile
   completes them (all band groups in a single call; xGMI rings are per-link bound, so fewer/larger messages).
@@ -24,11 +24,23 @@ import torch.distributed as dist
 KEYS = ("aI", "aI_sl", "aI_sh", "totals")  # packed in this order into one message per column tile
 
 
-def block_range(n, rank, world):
-    """Contiguous balanced block [lo, hi) of ``n`` items for ``rank`` of ``world`` (first ``n % world`` ranks get one more)."""
+def block_range(n, rank, world, unit=1):
+    """Contiguous balanced block [lo, hi) of ``n`` items for ``rank`` of ``world`` (first ranks get one more).  ``unit > 1``
+    hands the items out in groups of ``unit`` (``n`` must be a multiple of it)."""
+    if unit > 1:
+        lo, hi = block_range(n // unit, rank, world)
+        return lo * unit, hi * unit
     q, r = divmod(n, world)
     lo = rank * q + min(rank, r)
     return lo, lo + q + (1 if rank < r else 0)
+
+
+def band_block_range(nb, rank, world):
+    """This rank's bands.  An even number of bands is dealt in PAIRS, so that every shard is even (300 bands on 8 ranks ->
+    38 x 6 + 36 x 2 instead of 38 x 4 + 37 x 4: the largest shard is the same, but the kernels' 16-byte-per-lane fused flush needs
+    an even band count -- an odd shard runs the generic flush at 0.75 of the rate, tools/ab_narrow.py -- and the slowest rank sets
+    the step time)."""
+    return block_range(nb, rank, world, unit=2 if nb % 2 == 0 and nb >= 2 * world else 1)
 
 
 def _world(group):
@@ -87,7 +99,7 @@ class BandShardPlan:
         self.scheme, self.group = scheme, group
         self.world, self.rank = _world(group)
         self.ncol, self.nz = cols.ncol, cols.nz
-        self.band_range = block_range(bands.nb, self.rank, self.world)
+        self.band_range = band_block_range(bands.nb, self.rank, self.world)
         lo, hi = self.band_range
         b = bands.band_slice(lo, hi)
         bw = band_w[:, lo:hi].contiguous()

@@ -326,7 +326,8 @@ _TRI_PATHS = {"default": {}, "k_tri_tile": {10: 1}, "k_tri_tile M8 T8": {10: 1, 
 
 
 @pytest.mark.parametrize("scheme", ["2s", "4s", "bl", "g77", "bf", "n79", "zq"])
-@pytest.mark.parametrize("shape", [(23, 300, 60), (9, 107, 61), (6, 64, 13), (5, 128, 60), (3, 600, 33), (4, 255, 100), (7, 300, 7)])
+@pytest.mark.parametrize("shape", [(23, 300, 60), (9, 107, 61), (6, 64, 13), (5, 128, 60), (3, 600, 33), (4, 255, 100), (7, 300, 7),
+                                   (9, 38, 100), (7, 37, 60), (130, 36, 61), (5, 16, 30), (6, 21, 12)])  # + the narrow band shards
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_every_kernel_family_gives_the_same_bits(scheme, shape, dtype):
     """The wave-specialised pipelines (double-buffered, register-staged, generic flush), the all-waves tile kernels and the

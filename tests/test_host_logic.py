@@ -162,3 +162,16 @@ def test_no_silent_cpu_path():
 
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Model("2s").run()
+
+
+def test_band_partition_deals_pairs():
+    """300 bands on 8 ranks -> 38 x 6 + 36 x 2 (every shard even: the fused 16-byte flush applies on every rank), contiguous and
+    complete; odd totals and tiny spectra fall back to single bands."""
+    from crt1d_amd.dist import band_block_range, block_range
+
+    r = [band_block_range(300, k, 8) for k in range(8)]
+    assert [hi - lo for lo, hi in r] == [38] * 6 + [36] * 2
+    assert r[0][0] == 0 and r[-1][1] == 300 and all(r[i][1] == r[i + 1][0] for i in range(7))
+    assert [band_block_range(9, k, 2) for k in range(2)] == [(0, 5), (5, 9)]
+    assert [band_block_range(10, k, 8)[1] - band_block_range(10, k, 8)[0] for k in range(8)] == [2, 2, 1, 1, 1, 1, 1, 1]
+    assert [block_range(7, k, 3) for k in range(3)] == [(0, 3), (3, 5), (5, 7)]
