@@ -23,6 +23,7 @@ namespace {
 // Wave sums by DPP (wave_sum_lane63), one LDS slot per wave and level; the levels are processed in chunks of BS_CH whose loads
 // are all issued before the arithmetic (24 rows in flight per thread), a double-buffered partial-sum area needs one LDS-only
 // barrier per chunk, and the first BS_CH * ngroup threads turn the partials of the previous chunk into outputs.
+typedef double d2 __attribute__((ext_vector_type(2)));
 constexpr int MAXG = 4;
 constexpr int BS_CH = 8;
 
@@ -360,10 +361,119 @@ __global__ __launch_bounds__(256) void k_absorb(AbsArgs a) {
   }
 }
 
+// k_absorb_tile (even nb, 16-byte aligned arrays): a column's seven outputs are each ONE contiguous run of (nz-1) nb doubles, so
+// the kernel walks the flat element index with 16 bytes per lane -- every wave store is a contiguous, line-aligned 1 KiB whatever nb
+// is (with lanes on bands a 300-band row starts and ends inside a 128-B line: 0.50 of the HBM peak).  The three input profiles go
+// through an LDS ring of T + 1 rows: each round loads T new rows (one contiguous run per array, 16 bytes per lane), the row on top
+// of the previous round stays where it is, so every input byte is read exactly once.  Level factors and (1 - r - t) come from LDS.
+__global__ __launch_bounds__(256) void k_absorb_tile(AbsArgs a, int T) {
+  extern __shared__ double lds[];
+  const int c = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int nz = a.nz, nb = a.nb, nl = nz - 1, nb2 = nb >> 1, NS = T + 1;
+  double* fsl = lds;           // [nl]
+  double* absd = lds + nl;     // [nl]
+  double* la = lds + 2 * nl;   // [nb]
+  d2* ring = reinterpret_cast<d2*>(lds + 2 * nl + nb);  // [3][NS][nb2]
+  const double psi = a.psi[c];
+  const int kind = a.g_kind[c];
+  const double G = (kind == CRT_G_TABLE) ? a.g_at_psi[c] : G_closed(kind, a.g_param ? a.g_param[c] : 0.0, cos(psi), sin(psi));
+  const double Kb = G / cos(psi);
+  const double* lai = a.lai + (long long)c * nz;
+  for (int k = tid; k < nl; k += nthr) {
+    const double lm = (lai[k] + lai[k + 1]) / 2;       // model.py:601
+    const double f = exp(-Kb * lm);                    // :602
+    fsl[k] = f;
+    absd[k] = 1 - exp(-Kb * (lai[k] - lai[k + 1]));    // :619
+    a.laim[(long long)c * nl + k] = lm;
+    a.f_slm[(long long)c * nl + k] = f;
+  }
+  for (int b = tid; b < nb; b += nthr)
+    la[b] = 1 - (a.leaf_r[(long long)c * a.col_stride + b] + a.leaf_t[(long long)c * a.col_stride + b]);  // :584
+  const long long cb = (long long)c * nz * nb, cm = (long long)c * nl * nb;
+  const d2* R2 = reinterpret_cast<const d2*>(a.I_dr + cb);
+  const d2* D2 = reinterpret_cast<const d2*>(a.I_df_d + cb);
+  const d2* U2 = reinterpret_cast<const d2*>(a.I_df_u + cb);
+  const int dt = nthr / nb2, dp = nthr - dt * nb2;       // one round of the workgroup advances (dt rows, dp pairs)
+  const int t00 = tid / nb2, p00 = tid - t00 * nb2;
+  // row 0 of the column into slot 0
+  for (int p = tid; p < nb2; p += nthr) {
+    ring[p] = R2[p];
+    ring[NS * nb2 + p] = D2[p];
+    ring[2 * NS * nb2 + p] = U2[p];
+  }
+  int base = 0;  // ring slot of the row below the current chunk (level k0)
+  for (int k0 = 0; k0 < nl; k0 += T) {
+    const int nlev = min(T, nl - k0), n2 = nlev * nb2;
+    // rows k0+1 .. k0+nlev -> slots base+1 .. base+nlev (mod NS): one contiguous run of nlev * nb doubles per array
+    {
+      const long long g0 = (long long)(k0 + 1) * nb2;
+      int t = t00, p = p00;
+      for (int i2 = tid; i2 < n2; i2 += nthr) {
+        int slot = base + 1 + t;
+        if (slot >= NS) slot -= NS;
+        const int li = slot * nb2 + p;
+        ring[li] = __builtin_nontemporal_load(R2 + g0 + i2);
+        ring[NS * nb2 + li] = __builtin_nontemporal_load(D2 + g0 + i2);
+        ring[2 * NS * nb2 + li] = __builtin_nontemporal_load(U2 + g0 + i2);
+        p += dp;
+        t += dt;
+        if (p >= nb2) {
+          p -= nb2;
+          ++t;
+        }
+      }
+    }
+    __syncthreads();
+    {
+      int t = t00, p = p00;
+      const long long o0 = (cm >> 1) + (long long)k0 * nb2;
+      for (int i2 = tid; i2 < n2; i2 += nthr) {
+        int s0 = base + t;
+        if (s0 >= NS) s0 -= NS;
+        int s1 = s0 + 1;
+        if (s1 >= NS) s1 -= NS;
+        const int l0 = s0 * nb2 + p, l1 = s1 * nb2 + p;
+        const d2 r0 = ring[l0], r1 = ring[l1], d0 = ring[NS * nb2 + l0], d1 = ring[NS * nb2 + l1], u0 = ring[2 * NS * nb2 + l0],
+                 u1 = ring[2 * NS * nb2 + l1];
+        const double f = fsl[k0 + t], ab = absd[k0 + t];
+        const d2 l = reinterpret_cast<const d2*>(la)[p];
+        d2 av, adr, adf, sl, dsl, dsh;
+        av.x = r1.x - r0.x + d1.x - d0.x + u0.x - u1.x;   // :609
+        av.y = r1.y - r0.y + d1.y - d0.y + u0.y - u1.y;
+        adr.x = r1.x * ab * l.x;                          // :617-621
+        adr.y = r1.y * ab * l.y;
+        adf.x = av.x - adr.x;                             // :628
+        adf.y = av.y - adr.y;
+        dsl.x = adf.x * f;                                // :631-632
+        dsl.y = adf.y * f;
+        dsh.x = adf.x * (1 - f);
+        dsh.y = adf.y * (1 - f);
+        sl.x = dsl.x + adr.x;
+        sl.y = dsl.y + adr.y;
+        const long long o = o0 + i2;
+        reinterpret_cast<d2*>(a.o[0])[o] = av;
+        reinterpret_cast<d2*>(a.o[1])[o] = adf;
+        reinterpret_cast<d2*>(a.o[2])[o] = adr;
+        reinterpret_cast<d2*>(a.o[3])[o] = dsh;
+        reinterpret_cast<d2*>(a.o[4])[o] = sl;
+        reinterpret_cast<d2*>(a.o[5])[o] = dsl;
+        reinterpret_cast<d2*>(a.o[6])[o] = dsh;
+        p += dp;
+        t += dt;
+        if (p >= nb2) {
+          p -= nb2;
+          ++t;
+        }
+      }
+    }
+    base += nlev;
+    if (base >= NS) base -= NS;
+    lds_barrier();  // all reads of this chunk's slots are done before the next round overwrites them (LDS only: the stores keep flowing)
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // bandwidth probes: plain 16-B-per-lane streaming fill / copy, grid-stride
-typedef double d2 __attribute__((ext_vector_type(2)));
-
 __global__ __launch_bounds__(256) void k_fill(d2* dst, size_t n2, double v) {
   d2 t;
   t.x = v;
@@ -660,7 +770,18 @@ int crt_hip_absorb_f64(const crt_columns* cols, const crt_bands* bands, const do
   }
   a.laim = laim;
   a.f_slm = f_slm;
-  hipLaunchKernelGGL(k_absorb, dim3(a.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  bool flat = a.nb % 2 == 0 && a.col_stride % 2 == 0 && (long long)a.nz * a.nb < (1ll << 31);
+  const void* ptrs[] = {I_dr, I_df_d, I_df_u, a.o[0], a.o[1], a.o[2], a.o[3], a.o[4], a.o[5], a.o[6]};
+  for (const void* q : ptrs)
+    if (reinterpret_cast<uintptr_t>(q) & 15) flat = false;
+  // ring of T + 1 rows of the three inputs: T rows per round, as many as keep the workgroup at ~40 KB of LDS (4 per CU)
+  int T = (int)((40 * 1024 / sizeof(double) - 2 * (a.nz - 1) - a.nb) / (3 * (size_t)a.nb)) - 1;
+  T = std::max(1, std::min(T, std::min(16, a.nz - 1)));
+  const size_t shf = (size_t)(2 * (a.nz - 1) + a.nb + 3 * (T + 1) * a.nb) * sizeof(double);
+  if (flat && a.nb >= 2 && shf <= 64 * 1024)
+    hipLaunchKernelGGL(k_absorb_tile, dim3(a.ncol), dim3(256), shf, static_cast<hipStream_t>(stream), a, T);
+  else
+    hipLaunchKernelGGL(k_absorb, dim3(a.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 

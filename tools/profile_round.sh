@@ -1,15 +1,56 @@
 #!/bin/bash
-# Round evidence (run on the GPU box from the repo root): rocprofv3 kernel-trace stats of the bench command for the headline
-# (--placement none: every launch of the run then writes the same allocation, so that the rocprof average and the HIP-event average
-#  of bench.py describe the same thing; with the placement search the stats would also average its slower candidate allocations)
-# scheme and the two tridiagonal ones, then WRITE_SIZE / FETCH_SIZE in separate counter-only passes.  Output: gpurun_out/prof_*.
+# Round evidence (run on the GPU box from the repo root): for every kernel the repo makes a claim about,
+#   pass A  rocprofv3 --kernel-trace --stats          of the bench command (per-kernel average duration)
+#   pass B  rocprofv3 --pmc WRITE_SIZE --kernel-trace (separate pass, counters only)
+#   pass C  rocprofv3 --pmc FETCH_SIZE --kernel-trace (separate pass; gfx950: doubled when summarised)
+#   pass D  SQ busy / wait / VALU counters for the kernels that are NOT HBM-bound (zq_pa, f32 storage, integrated)
+# The program follows `--` directly (python3 <script>); no traces are combined with --pmc.  Output: gpurun_out/prof_<tag>/<case>/<pass>/.
+# usage: bash tools/profile_round.sh <tag> [case-name-filter]
 R=${GRAFT_REPO_ROOT:-$PWD}
+TAG=${1:-r02}
+ONLY=${2:-}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for S in 2s n79 zq; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats_$S -- python3 $R/bench.py --scheme $S --steps 20 --warmup 5 --no-cpu-baseline --placement none > $R/gpurun_out/prof_stats_$S.json 2> $R/gpurun_out/prof_stats_$S.err || exit 1
+B="--steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-pcie"
+# name | pmc passes wanted (wf = WRITE+FETCH, sq = + SQ pass) | command after `python3`
+CASES=(
+"2s|wf|$R/bench.py --scheme 2s $B"
+"4s|wf|$R/bench.py --scheme 4s $B"
+"bl|wf|$R/bench.py --scheme bl $B"
+"g77|wf|$R/bench.py --scheme g77 $B"
+"bf|wf|$R/bench.py --scheme bf $B"
+"n79|wf|$R/bench.py --scheme n79 $B"
+"zq|wf|$R/bench.py --scheme zq $B"
+"zq_pa|wfsq|$R/bench.py --scheme zq_pa $B"
+"zq_nz100|wf|$R/bench.py --scheme zq --nz 100 --ncol 6000 $B"
+"2s_f32|wfsq|$R/bench.py --scheme 2s --dtype f32 $B"
+"n79_f32|wfsq|$R/bench.py --scheme n79 --dtype f32 $B"
+"2s_nb107|wf|$R/bench.py --scheme 2s --nb 107 --ncol 30000 $B"
+"n79_nb107|wf|$R/bench.py --scheme n79 --nb 107 --ncol 30000 $B"
+"zq_nb107|wf|$R/bench.py --scheme zq --nb 107 --ncol 30000 $B"
+"zq_nb38_nz100|wf|$R/bench.py --scheme zq --nb 38 --nz 100 --ncol 100000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
+"2s_nb38|wf|$R/bench.py --scheme 2s --nb 38 --ncol 200000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
+"zq_nb12_wave|wf|$R/bench.py --scheme zq --nb 12 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
+"2s_nb12_direct|wf|$R/bench.py --scheme 2s --nb 12 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
+"2s_integrated|wfsq|$R/bench.py --scheme 2s --variant integrated $B"
+"n79_integrated|wfsq|$R/bench.py --scheme n79 --variant integrated $B"
+"zq_integrated|wfsq|$R/bench.py --scheme zq --variant integrated $B"
+"band_zq|wf|$R/bench.py --partition band --ncol 20000 --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline"
+"epilogue|wf|$R/tools/epilogue_bench.py 10000 300 60"
+)
+for entry in "${CASES[@]}"; do
+  IFS='|' read -r name passes cmd <<< "$entry"
+  if [ -n "$ONLY" ] && ! [[ "$name" =~ $ONLY ]]; then continue; fi
+  d=$OUT/$name
+  mkdir -p $d
+  echo "== $name" | tee -a $OUT/progress.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d/stats -- python3 $cmd > $d/stats.json 2> $d/stats.err || { echo "stats pass failed for $name" | tee -a $OUT/progress.log; continue; }
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $d/pmc_WRITE_SIZE -- python3 $cmd > $d/pmc_WRITE_SIZE.log 2>&1 || echo "WRITE_SIZE pass failed for $name" | tee -a $OUT/progress.log
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $d/pmc_FETCH_SIZE -- python3 $cmd > $d/pmc_FETCH_SIZE.log 2>&1 || echo "FETCH_SIZE pass failed for $name" | tee -a $OUT/progress.log
+  if [[ "$passes" == *sq* ]]; then
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $d/pmc_SQ -- python3 $cmd > $d/pmc_SQ.log 2>&1 || echo "SQ pass failed for $name" | tee -a $OUT/progress.log
+  fi
 done
-for S in 2s n79 zq; do
-  for C in WRITE_SIZE FETCH_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/prof_pmc_${C}_$S -- python3 $R/bench.py --scheme $S --steps 3 --warmup 1 --no-cpu-baseline --placement none > $R/gpurun_out/prof_pmc_${C}_$S.log 2>&1 || exit 1
-  done
-done
+python3 $R/tools/summarize_profiles.py $OUT > $OUT/summary.json 2> $OUT/summary.err
+echo "done" | tee -a $OUT/progress.log

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 output of tools/profile_round.sh: per case the dominant crt:: kernel's average duration (kernel-trace stats),
+HBM bytes per launch from the separate --pmc passes (WRITE_SIZE exact, FETCH_SIZE doubled: gfx950 counts 128-B requests at 64 B,
+/opt/skills/guides/MI355X_MICROARCH.md section HBM; counter values are KiB), and SQ busy/wait shares where collected.
+usage: summarize_profiles.py <prof dir>   -> JSON on stdout (also small CSV copies next to it for profiles/)"""
+import csv
+import glob
+import json
+import os
+import sys
+
+SKIP = ("k_fill", "k_copy", "k_probe_cols", "k_colpre", "__amd_rocclr", "at::native", "Cijk", "elementwise", "vectorized")
+
+
+def find(d, pat):
+    r = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+def short(name):
+    n = name.replace("crt::(anonymous namespace)::", "").replace("crt::", "").replace("void ", "")
+    return n.split("(")[0] if len(n) > 150 else n
+
+
+def main(root):
+    out = {}
+    for case in sorted(os.listdir(root)):
+        d = os.path.join(root, case)
+        if not os.path.isdir(d):
+            continue
+        e = {}
+        st = find(os.path.join(d, "stats"), "*kernel_stats.csv")
+        kernels = {}
+        if st:
+            for r in csv.DictReader(open(st)):
+                kernels[r["Name"]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
+                                      "max_us": float(r["MaxNs"]) / 1e3, "total_ms": float(r["TotalDurationNs"]) / 1e6}
+        ours = {k: v for k, v in kernels.items() if not any(s in k for s in SKIP)}
+        e["kernels"] = {short(k): v for k, v in sorted(ours.items(), key=lambda kv: -kv[1]["total_ms"])}
+        dom = max(ours, key=lambda k: ours[k]["total_ms"]) if ours else None
+        e["dominant"] = short(dom) if dom else None
+        try:
+            line = [ln for ln in open(os.path.join(d, "stats.json")) if ln.startswith("{")]
+            if line:
+                b = json.loads(line[0])
+                if "roofline" in b:
+                    e["bench"] = {k: b["roofline"].get(k) for k in ("kernel", "kernel_ms_avg", "achieved", "frac", "algorithmic_bytes_per_launch", "launch_shape", "frac_of_measured_fill")}
+                    e["bench"]["ms_per_step"] = b["ms_per_step"]
+                else:
+                    e["bench"] = b
+        except Exception:
+            pass
+        for cname in ("WRITE_SIZE", "FETCH_SIZE"):
+            f = find(os.path.join(d, "pmc_" + cname), "*counter_collection.csv")
+            if not f:
+                continue
+            per = {}
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != cname:
+                    continue
+                per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            for k, v in per.items():
+                if any(s in k for s in SKIP):
+                    continue
+                kk = short(k)
+                e.setdefault("pmc", {}).setdefault(kk, {})[cname + "_KiB_mean"] = sum(v) / len(v)
+        for kk, c in e.get("pmc", {}).items():
+            w, f = c.get("WRITE_SIZE_KiB_mean"), c.get("FETCH_SIZE_KiB_mean")
+            if w is not None and f is not None:
+                c["hbm_bytes_per_launch"] = int(w * 1024 + 2 * f * 1024)
+        f = find(os.path.join(d, "pmc_SQ"), "*counter_collection.csv")
+        if f:
+            acc = {}
+            for r in csv.DictReader(open(f)):
+                if any(s in r["Kernel_Name"] for s in SKIP):
+                    continue
+                acc.setdefault(short(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            sq = {}
+            for k, c in acc.items():
+                m = {n: sum(v) / len(v) for n, v in c.items()}
+                wc = m.get("SQ_WAVE_CYCLES") or 1.0
+                sq[k] = {"means": m, "share_of_wave_cycles": {n: round(m[n] / wc, 3) for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS") if n in m}}
+            e["sq"] = sq
+        if dom and "bench" in e and isinstance(e["bench"], dict) and e["bench"].get("algorithmic_bytes_per_launch"):
+            alg = e["bench"]["algorithmic_bytes_per_launch"]
+            e["rocprof_avg_ms"] = ours[dom]["avg_us"] / 1e3
+            e["rocprof_GBs"] = alg / (ours[dom]["avg_us"] * 1e-6) / 1e9
+            e["rocprof_frac_of_8TBs"] = e["rocprof_GBs"] / 8000.0
+            p = e.get("pmc", {}).get(short(dom), {})
+            if "hbm_bytes_per_launch" in p:
+                e["traffic_over_algorithmic"] = p["hbm_bytes_per_launch"] / alg
+        out[case] = e
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
