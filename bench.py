@@ -190,19 +190,21 @@ def cpu_baseline(scheme, nb, nz, budget_s=15.0):
     return out
 
 
-def load_pmc_traffic(scheme, ncol, nb, nz):
-    """HBM bytes per launch of the solve kernel from the committed rocprofv3 --pmc summary (separate WRITE_SIZE /
-    FETCH_SIZE passes of this same command, profiles/), if one exists for exactly this configuration."""
+def load_pmc_traffic(scheme, shape, f32=False, variant="profiles"):
+    """HBM bytes per launch of the solve kernel from the committed rocprofv3 --pmc summary (separate WRITE_SIZE / FETCH_SIZE passes
+    of this same command, profiles/pmc_traffic.json), if one exists for exactly this scheme / storage type / variant / launch shape."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    want = scheme + ("_f32" if f32 else "") + ("_integrated" if variant == "integrated" else "")
     try:
         with open(p) as f:
             d = json.load(f)
-        e = d.get(scheme)
-        if e is None or e.get("shape") != [ncol, nb, nz]:
-            return None
-        return e.get("hbm_bytes_per_launch")
+        for e in d.get("entries", []):
+            base = e["case"].split("_nb")[0].split("_nz")[0]
+            if base == want and e.get("shape") == list(shape):
+                return e.get("hbm_bytes_per_launch")
     except Exception:
-        return None
+        pass
+    return None
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -561,7 +563,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": load_pmc_traffic(scheme, ncol_kernel, nb_kernel, nz) if (not f32 and a.variant == "profiles") else None,
+            "traffic": load_pmc_traffic(scheme, (ncol_kernel, nb_kernel, nz), f32, a.variant),
             "algorithmic_bytes_per_launch": alg_bytes,
             "bytes_per_solve": bps,
             "launch_shape": [ncol_kernel, nb_kernel, nz],

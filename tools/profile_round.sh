@@ -23,15 +23,15 @@ CASES=(
 "n79|wf|$R/bench.py --scheme n79 $B"
 "zq|wf|$R/bench.py --scheme zq $B"
 "zq_pa|wfsq|$R/bench.py --scheme zq_pa $B"
-"zq_nz100|wf|$R/bench.py --scheme zq --nz 100 --ncol 6000 $B"
+"zq_nz100|wfsq|$R/bench.py --scheme zq --nz 100 --ncol 6000 $B"
 "2s_f32|wfsq|$R/bench.py --scheme 2s --dtype f32 $B"
 "n79_f32|wfsq|$R/bench.py --scheme n79 --dtype f32 $B"
 "2s_nb107|wf|$R/bench.py --scheme 2s --nb 107 --ncol 30000 $B"
-"n79_nb107|wf|$R/bench.py --scheme n79 --nb 107 --ncol 30000 $B"
-"zq_nb107|wf|$R/bench.py --scheme zq --nb 107 --ncol 30000 $B"
+"n79_nb107|wfsq|$R/bench.py --scheme n79 --nb 107 --ncol 30000 $B"
+"zq_nb107|wfsq|$R/bench.py --scheme zq --nb 107 --ncol 30000 $B"
 "zq_nb38_nz100|wf|$R/bench.py --scheme zq --nb 38 --nz 100 --ncol 100000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
 "2s_nb38|wf|$R/bench.py --scheme 2s --nb 38 --ncol 200000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
-"zq_nb12_wave|wf|$R/bench.py --scheme zq --nb 12 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
+"zq_nb12_wave|wfsq|$R/bench.py --scheme zq --nb 12 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
 "2s_nb12_direct|wf|$R/bench.py --scheme 2s --nb 12 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
 "2s_integrated|wfsq|$R/bench.py --scheme 2s --variant integrated $B"
 "n79_integrated|wfsq|$R/bench.py --scheme n79 --variant integrated $B"
