@@ -18,7 +18,7 @@ struct TriN79 {
   double dn, up;  // back-substitution state (level k+1)
 
   __host__ __device__ static inline int rows(int nz) { return nz; }               // even rows
-  __host__ __device__ static inline int out_rows(int arr, int nz) { return arr >= 4 ? nz - 1 : nz; }
+  __host__ __device__ static constexpr int out_rows(int arr, int nz) { return arr >= 4 ? nz - 1 : nz; }
   __device__ inline double band_const() const { return swb; }
 
   template <typename TIO>
@@ -190,7 +190,7 @@ struct TriZq {
   double xd, xu;  // SWd0[li], SWu0[li] of the level above
 
   __host__ __device__ static inline int rows(int nz) { return nz + 1; }
-  __host__ __device__ static inline int out_rows(int, int nz) { return nz; }
+  __host__ __device__ static constexpr int out_rows(int, int nz) { return nz; }
   __device__ inline double band_const() const { return I_dr0; }
 
   template <typename TIO>
@@ -289,7 +289,7 @@ struct TriZq {
 struct TriZqPa : TriZq {
   static constexpr const char* NAME = "zq_pa grid";
   static constexpr int NOUT = 2;
-  __host__ __device__ static inline int out_rows(int, int nz) { return nz; }
+  __host__ __device__ static constexpr int out_rows(int, int nz) { return nz; }
   template <int ARR>
   __device__ static inline double value(const double*, int, int, double, double, const double* tile, int stride, int idx) {
     return tile[ARR * stride + idx];

@@ -37,6 +37,7 @@ struct TriCfg {
   int off_bc;   // LDS offsets in doubles: band constants
   int off_ck;   // checkpoints [nck][2][nthr]
   int off_tile; // tile [NST][T][nb]
+  int flat;     // odd nb: fused flat flush (flush_flat) instead of the per-array generic flush
 };
 
 // ------------------------------------------------------------------------------------------
@@ -82,6 +83,90 @@ __device__ inline void flush_arrays(const SolveArgs& a, const double* rec, const
   const int nr = min(j0 + T, S::out_rows(ARR, a.nz)) - j0;
   flush_array<S, TIO, ARR>(a, rec, bandc, tile, tstride, c, j0, nr, invmu, inv_nb, tid, nthr);
   if constexpr (ARR + 1 < S::NOUT) flush_arrays<S, TIO, ARR + 1>(a, rec, bandc, tile, tstride, c, j0, T, invmu, inv_nb, tid, nthr);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused FLAT flush for odd nb (round 2).  flush_arrays above walks every output array separately and derives (level, band) of
+// every element with a float division; at the reference's 107 bands that index arithmetic, not HBM, bounds the tridiagonal
+// kernels (0.59-0.65 of the peak, SQ counters in profiles/r02/rocprof/{n79,zq}_nb107).  Arrays with the same number of rows are
+// flat runs of identical length and alignment inside their buffers, so ONE walk over the element pairs of the tile serves all of
+// them: (level, band) advance incrementally, the staged values are read once (the compiler merges the LDS reads of the value<>()
+// expressions), and every array gets its 16-byte store.  Same expressions as flush_array -> same bits.
+// CLS = 0: arrays with nz rows, CLS = 1: arrays with nz - 1 rows (n79's per-leaf-area absorption).
+template <class S, typename TIO, int CLS, int ARR, class F>
+__device__ __forceinline__ void for_class(int nz, F&& f) {
+  if constexpr (ARR < S::NOUT) {
+    if constexpr ((S::out_rows(ARR, 8) == 8 ? 0 : 1) == CLS) f(std::integral_constant<int, ARR>{});
+    for_class<S, TIO, CLS, ARR + 1>(nz, f);
+  }
+}
+
+template <class S, typename TIO, int CLS>
+__device__ inline void flush_flat_class(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride,
+                                        int c, int j0, int T, double invmu, int tid, int nthr) {
+  typedef TIO vt __attribute__((ext_vector_type(2)));
+  const int nb = a.nb, nz = a.nz, rows = nz - CLS;
+  const int nr = min(j0 + T, rows) - j0;
+  if (nr <= 0) return;
+  const int n = nr * nb;
+  const long long g0 = ((long long)c * rows + j0) * nb;  // start of the run inside every array of the class (bases are pair-aligned: checked by the launcher)
+  const int mis = (int)(g0 & 1);
+  const int npair = (n - mis) >> 1;
+  const int step = 2 * nthr;
+  int e = mis + 2 * tid;
+  int t = (int)(((float)e + 0.5f) * (1.0f / (float)nb));
+  int b = e - t * nb;
+  if (b < 0) { --t; b += nb; }
+  if (b >= nb) { ++t; b -= nb; }
+  const int dt = step / nb, db = step - dt * nb;
+  for (int i = tid; i < npair; i += nthr) {
+    const bool wrap = b + 1 >= nb;
+    const int t2 = wrap ? t + 1 : t, b2 = wrap ? 0 : b + 1;
+    const double bcx = bandc[b], bcy = bandc[b2];
+    for_class<S, TIO, CLS, 0>(nz, [&](auto arr) {
+      constexpr int ARRI = decltype(arr)::value;
+      vt v;
+      v.x = (TIO)S::template value<ARRI>(rec, nz, j0 + t, bcx, invmu, tile, tstride, e);
+      v.y = (TIO)S::template value<ARRI>(rec, nz, j0 + t2, bcy, invmu, tile, tstride, e + 1);
+      *reinterpret_cast<vt*>(outp<TIO>(a.o[ARRI]) + g0 + e) = v;
+    });
+    e += step;
+    b += db;
+    t += dt;
+    if (b >= nb) {
+      b -= nb;
+      ++t;
+    }
+  }
+  if (tid == 0) {  // the unpaired elements at the two ends of the run
+    if (mis)
+      for_class<S, TIO, CLS, 0>(nz, [&](auto arr) {
+        constexpr int ARRI = decltype(arr)::value;
+        outp<TIO>(a.o[ARRI])[g0] = (TIO)S::template value<ARRI>(rec, nz, j0, bandc[0], invmu, tile, tstride, 0);
+      });
+    if ((n - mis) & 1) {
+      const int el = n - 1, tl = nr - 1, bl = nb - 1;
+      for_class<S, TIO, CLS, 0>(nz, [&](auto arr) {
+        constexpr int ARRI = decltype(arr)::value;
+        outp<TIO>(a.o[ARRI])[g0 + el] = (TIO)S::template value<ARRI>(rec, nz, j0 + tl, bandc[bl], invmu, tile, tstride, el);
+      });
+    }
+  }
+}
+
+template <class S, typename TIO>
+__device__ inline void flush_flat(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride, int c,
+                                  int j0, int T, double invmu, int tid, int nthr) {
+  flush_flat_class<S, TIO, 0>(a, rec, bandc, tile, tstride, c, j0, T, invmu, tid, nthr);
+  if constexpr (S::out_rows(S::NOUT - 1, 8) != 8) flush_flat_class<S, TIO, 1>(a, rec, bandc, tile, tstride, c, j0, T, invmu, tid, nthr);
+}
+
+// host side: may the flat fused flush be used?  Every output array must start on a pair boundary (2 * sizeof(TIO)).
+template <class S, typename TIO>
+inline bool flat_flush_ok(const SolveArgs& a) {
+  for (int i = 0; i < S::NOUT; ++i)
+    if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) return false;
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -202,6 +287,8 @@ __device__ __forceinline__ void tri_tile_body(const SolveArgs& a, const TriCfg& 
           lds_barrier();
           if constexpr (FUSED)
             flush_fused<S, TIO, T>(a, rec, bandc, tile, c, k, fm, invmu);
+          else if (cfg.flat)
+            flush_flat<S, TIO>(a, rec, bandc, tile, tstride, c, k, T, invmu, tid, nthr);
           else
             flush_arrays<S, TIO, 0>(a, rec, bandc, tile, tstride, c, k, T, invmu, inv_nb, tid, nthr);
           lds_barrier();
@@ -234,12 +321,13 @@ __global__ __launch_bounds__(MAXT) void k_tri_tile(SolveArgs a, TriCfg cfg) {
 template <class S, typename TIO, int M, int T, bool FUSED>
 int launch_mt(const SolveArgs& a, hipStream_t s, int nthr) {
   const int K = S::rows(a.nz);
-  TriCfg cfg;
+  TriCfg cfg{};
   cfg.T = T;
   cfg.nck = (K - 1) / M + 1;
   cfg.off_bc = (a.reclen + 1) & ~1;
   cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
   cfg.off_tile = cfg.off_ck + 2 * cfg.nck * nthr;
+  cfg.flat = !FUSED && a.tune[13] != 1 && flat_flush_ok<S, TIO>(a);
   const size_t sh = ((size_t)cfg.off_tile + (size_t)S::NST * T * a.nb) * sizeof(double);
   if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
   const void* fn = nthr <= 256 ? (const void*)k_tri_tile<S, TIO, M, T, 256, FUSED> : nthr <= 512 ? (const void*)k_tri_tile<S, TIO, M, T, 512, FUSED>
@@ -253,7 +341,7 @@ int launch_mt(const SolveArgs& a, hipStream_t s, int nthr) {
     hipLaunchKernelGGL((k_tri_tile<S, TIO, M, T, 512, FUSED>), grid, block, sh, s, a, cfg);
   else
     hipLaunchKernelGGL((k_tri_tile<S, TIO, M, T, 1024, FUSED>), grid, block, sh, s, a, cfg);
-  note_kernel("k_tri_tile<%s,%s>%s M=%d T=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", FUSED ? "" : " generic-flush", M, T, sh);
+  note_kernel("k_tri_tile<%s,%s>%s M=%d T=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", FUSED ? "" : cfg.flat ? " flat-flush" : " generic-flush", M, T, sh);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 
@@ -402,6 +490,7 @@ struct PipeCfg {
   int ncomp;     // compute threads (multiple of 64); threads beyond are store threads
   int nck;
   int off_bc, off_ck, off_tile;  // LDS offsets in doubles; tile = [2][NST][T][nb]
+  int flat;  // generic store role: fused flat flush (flush_flat) instead of the per-array generic flush
   // zq_pa with the interpolation fused into the store waves (tri_zqpa.hip): the caller's level count and output arrays
   int nz_out, off_halo;
   void* out[4];
@@ -565,7 +654,10 @@ __device__ __forceinline__ void tri_pipe_store_generic(const SolveArgs& a, const
       const int k = k0 + i;
       if (k > kend) continue;
       lds_barrier();  // tile `buf` is complete
-      flush_arrays<S, TIO, 0>(a, rec, bandc, tile + buf * bstride, tstride, c, k, min(T, kend - k + 1), invmu, inv_nb, sid, nst);
+      if (cfg.flat)
+        flush_flat<S, TIO>(a, rec, bandc, tile + buf * bstride, tstride, c, k, min(T, kend - k + 1), invmu, sid, nst);
+      else
+        flush_arrays<S, TIO, 0>(a, rec, bandc, tile + buf * bstride, tstride, c, k, min(T, kend - k + 1), invmu, inv_nb, sid, nst);
       buf ^= 1;
     }
   }
@@ -664,12 +756,13 @@ int launch_pipe_generic(const SolveArgs& a, hipStream_t s, int nstore_waves) {
   const int nthr = ncomp + 64 * nstore_waves;
   if (nthr > 512) return CRT_ERR_UNSUPPORTED;  // instantiated for narrow spectra only (the odd-nb case that matters: nb = 107)
   const int K = S::rows(a.nz);
-  PipeCfg cfg;
+  PipeCfg cfg{};
   cfg.ncomp = ncomp;
   cfg.nck = (K - 1) / M + 1;
   cfg.off_bc = (a.reclen + 1) & ~1;
   cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
   cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
+  cfg.flat = a.tune[13] != 1 && flat_flush_ok<S, TIO>(a);
   const size_t sh = ((size_t)cfg.off_tile + (size_t)2 * S::NST * T * a.nb) * sizeof(double);
   if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
   auto kern = k_tri_pipe<S, TIO, M, T, 512, -1>;
@@ -677,7 +770,8 @@ int launch_pipe_generic(const SolveArgs& a, hipStream_t s, int nstore_waves) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
     return CRT_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, cfg);
-  note_kernel("k_tri_pipe<%s,%s> generic-flush M=%d T=%d store_waves=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", M, T, nstore_waves, sh);
+  note_kernel("k_tri_pipe<%s,%s> %s M=%d T=%d store_waves=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", cfg.flat ? "flat-flush" : "generic-flush", M, T,
+              nstore_waves, sh);
   return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
 }
 
@@ -688,7 +782,7 @@ int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves, bool reg
   if (nthr > 1024) return CRT_ERR_UNSUPPORTED;
   if (regstage && T * (a.nb / 2) > PIPE_RS * 64 * nstore_waves) return CRT_ERR_UNSUPPORTED;
   const int K = S::rows(a.nz);
-  PipeCfg cfg;
+  PipeCfg cfg{};
   cfg.ncomp = ncomp;
   cfg.nck = (K - 1) / M + 1;
   cfg.off_bc = (a.reclen + 1) & ~1;
@@ -761,7 +855,10 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 16
   // waves once the spectrum is wide (tools/ab_tri_odd.py, k_tri_tile -> pipeline with 2 store waves: nb=107 n79 1.81 -> 1.90 ms,
   // zq 2.35 -> 2.29, zq nz=100 3.00 -> 2.22; nb=255 n79 1.60 -> 2.39, zq 2.25 -> 2.86), so only zq on narrow spectra takes it
   // (tune key 10 = 4 forces it for any scheme and nb).
-  if (!fused && g_tri_tune[2] != 1 && g_tri_tune[0] == 0 && ((nthr <= 128 && S::NOUT == 7) || g_tri_tune[2] == 4)) {
+  // With the fused flat flush (round 2; tools/ab_flat.py, 3e4 x 107 x 60: zq 2.25 -> 1.80 ms, n79 1.77 -> 1.61 in k_tri_tile, 1.57 in
+  // the pipeline) the narrow pipeline pays for n79 as well.
+  const bool flat_ok = a.tune[13] != 1 && flat_flush_ok<S, TIO>(a);
+  if (!fused && g_tri_tune[2] != 1 && g_tri_tune[0] == 0 && ((nthr <= 128 && (S::NOUT == 7 || flat_ok)) || g_tri_tune[2] == 4)) {
     const int nsw = g_tri_tune[3] > 0 ? g_tri_tune[3] : (nthr == 64 ? 1 : 2);
     int st = launch_pipe_generic<S, TIO, 12, 4>(a, s, nsw);
     if (st == CRT_ERR_UNSUPPORTED) st = launch_pipe_generic<S, TIO, 16, 4>(a, s, nsw);

@@ -181,7 +181,7 @@ int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
   SolveArgs g = a;  // computational-grid solve: nz := Mg; the outputs go through PipeCfg
   g.nz = Mg;
   for (int i = 0; i < 7; ++i) g.o[i] = nullptr;
-  PipeCfg cfg;
+  PipeCfg cfg{};
   cfg.ncomp = ncomp;
   cfg.nck = Mg / M + 1;  // K = Mg + 1 rows
   cfg.off_bc = (a.reclen + 1) & ~1;
