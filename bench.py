@@ -282,6 +282,8 @@ def parse_args(argv):
     ap.add_argument("--variant", default="profiles", choices=["profiles", "integrated"],
                     help="'integrated': fused solve + absorption + band integrals (crt_hip_integrated_f64), no profiles written; "
                          "a separately reported variant with its own byte count, NOT the headline")
+    ap.add_argument("--compare-plain", action="store_true", help="also time the solve kernel on torch.empty outputs (roofline.kernel_ms_avg_torch_empty_outputs); "
+                    "off by default so that a rocprofv3 average of the default command describes ONE allocation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the H2D + step + D2H measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -402,13 +404,15 @@ def main():
         from crt1d_amd import dist as cdist
         from crt1d_amd import spectra
 
-        if a.variant != "profiles" or f32:
-            raise SystemExit("--partition band runs the fp64 profile path (solve + epilogue + all-reduce)")
+        if f32:
+            raise SystemExit("--partition band runs the fp64 path")
         d = synth.make_columns(ncol, nb, nz, seed=1234)  # the SAME columns on every rank: K0 is replicated, the bands are sharded
         cols = batched.Columns.from_host(d, dev)
         bands = batched.Bands.from_host(d, dev)
         bw = torch.as_tensor(spectra.band_weights(d["wle"])).to(dev)
-        plan = cdist.BandShardPlan(scheme, cols, bands, bw, column_tiles=a.column_tiles, share_profiles=True, placement=a.placement)
+        # --variant integrated: the fused kernel (crt_hip_integrated_f64) forms the band sums without writing any profile
+        plan = cdist.BandShardPlan(scheme, cols, bands, bw, column_tiles=a.column_tiles, share_profiles=True, placement=a.placement,
+                                   keep_profiles=a.variant == "profiles")
         del bands
         nb_local = plan.band_range[1] - plan.band_range[0]
         res_holder = {}
@@ -528,6 +532,24 @@ def main():
         torch.cuda.synchronize(dev)
         k0_ms = e0.elapsed_time(e1) / 10
 
+        # the same kernel on plain torch.empty outputs (whatever the driver hands out: the round-1 "placement lottery"), for comparison
+        k_ms_plain = None
+        if a.compare_plain and world == 1 and not band and a.variant == "profiles" and a.placement == "auto" and getattr(main_plan, "placement_report", None):
+            try:
+                plain = batched.Plan(scheme, cols, bands, placement="none", workspace=main_plan.workspace)
+                for _ in range(3):
+                    plain(flags=_lib.FLAG_SKIP_PRECOMPUTE)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(20):
+                    plain(stream, flags=_lib.FLAG_SKIP_PRECOMPUTE)
+                e1.record(stream)
+                torch.cuda.synchronize(dev)
+                k_ms_plain = e0.elapsed_time(e1) / 20
+                del plain
+            except Exception as e:
+                print(f"plain-allocation comparison failed: {e!r}", file=sys.stderr)
+
         bps = bytes_per_solve(scheme, nz, 4 if f32 else 8)
         if a.variant == "integrated":  # B = s n_in + s n_red (nz-1) / nb  (SURVEY 8(d)); n_red = 3 quantities x NG groups
             bps = 8 * N_IO[scheme][0] + 8 * 3 * NG * (nz - 1) / nb
@@ -571,6 +593,7 @@ def main():
             "kernel_ms_median": k_ms_med,
             "kernel_ms_min": kt[0],
             "kernel_ms_max": kt[-1],
+            "kernel_ms_avg_torch_empty_outputs": k_ms_plain,
             "k0_ms": k0_ms,
             "measured_fill_GBs": fill_gbs,
             "measured_copy_GBs": copy_gbs,
@@ -629,7 +652,8 @@ def main():
                          + (" (BASELINE.json configs[3] shape)" if (scheme, ncol, nb, nz, band) == ("zq", 100000, 300, 100, True) else "")),
             "scheme": scheme, ("ncol_total" if band else "ncol_per_gpu"): ncol, "nb": nb, "nz": nz,
             "partition": extra.pop("partition", "column blocks, no collective"),
-            "step": ("K0 column precompute + solve kernel via crt_hip_%s_f64" % scheme) + (" + crt_hip_absorb_bandsum_f64 + all-reduce, per column tile" if band else ""),
+            "step": (("K0 column precompute + solve kernel via crt_hip_%s_f64" % scheme) + (" + crt_hip_absorb_bandsum_f64 + all-reduce, per column tile" if band else ""))
+                    if a.variant == "profiles" else ("K0 + crt_hip_integrated_f64 (no profiles written)" + (" + all-reduce, per column tile" if band else "")),
             "output_placement": getattr(main_plan, "placement_report", None) if a.placement == "auto" else "torch.empty (--placement none)",
         },
     }

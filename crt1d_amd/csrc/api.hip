@@ -794,6 +794,10 @@ int crt_hip_tau_d_f64(const double* kb_nodes, const double* L, int64_t n, int32_
 
 const char* crt_hip_last_kernel(void) { return last_kernel(); }
 
+// The fill probe is a YARDSTICK, not a ceiling: a linear fill writes one narrow window of memory at a time, i.e. into one class
+// of physical memory (csrc/buffers.hip), and is subject to the same single-class limit as the column pattern -- 6.2-6.6 TB/s with
+// this 256-workgroup grid, 4.2-4.5 TB/s with 2048 workgroups (tools/chunk_probe.hip: the wider window of the larger grid is worse,
+// so the grid was NOT enlarged) -- while the solve kernels' pattern reaches 7.0 TB/s into a class-balanced set of arrays.
 int crt_hip_probe_fill_f64(double* dst, size_t n, double value, crt_stream_t stream) {
   if (!dst || n == 0 || (n & 1) || (reinterpret_cast<uintptr_t>(dst) & 15)) return CRT_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<d2*>(dst), n / 2, value);

@@ -327,6 +327,26 @@ struct IntLds {
 template <bool ROWS>
 __device__ inline void int_accumulate(const IntLds& L, int nwave, int wave, int lane, int nz, int j, int ng, const double (&w)[INT_MAXG],
                                       bool active, double idr, double dn, double up) {
+  if constexpr (!ROWS) {
+    // wave totals of all (up to four) band groups with ONE wave_sum4: 21 VALU instructions per level instead of 18 per group
+    // (w[g] = 0 for g >= ngroup and for inactive lanes)
+    const int g = wave_sum4_slot(lane >> 4);
+    const bool writer = (lane & 15) == 0 && g < ng;
+    const double net = active ? idr + dn - up : 0.0;
+    const double z = wave_sum4(w[0] * net, w[1] * net, w[2] * net, w[3] * net);
+    if (writer) L.part[(j * nwave + wave) * INT_MAXG + g] = z;
+    if (j == 0 || j == nz - 1) {
+      const int e = j == 0 ? 0 : 1;
+      const double dd = active ? idr + dn : 0.0, uu = active ? up : 0.0;
+      const double z0 = wave_sum4(w[0] * dd, w[1] * dd, w[2] * dd, w[3] * dd);
+      const double z1 = wave_sum4(w[0] * uu, w[1] * uu, w[2] * uu, w[3] * uu);
+      if (writer) {
+        L.ends[((e * nwave + wave) * 2 + 0) * INT_MAXG + g] = z0;
+        L.ends[((e * nwave + wave) * 2 + 1) * INT_MAXG + g] = z1;
+      }
+    }
+    return;
+  }
   const int nslot = ROWS ? nwave * 4 : nwave;
   const int slot = ROWS ? wave * 4 + (lane >> 4) : wave;
   const bool writer = ROWS ? (lane & 15) == 0 : lane == 63;

@@ -941,7 +941,9 @@ int launch_int(const SolveArgs& a, const IntArgs& ia, hipStream_t s) {
   const int rec_dbl = (a.reclen + 1) & ~1;
   // per-row partials (4 DPP steps per value) while they leave three workgroups per CU, else per-wave totals (6 steps):
   // measured 2s 1e4x300x60: rows 0.625 ms, wave totals 0.80 ms, __shfl_xor butterflies 1.59 ms
-  const bool rows = (rec_dbl + int_lds_doubles(a.nz, nthr / 64, true)) * sizeof(double) <= 52 * 1024;
+  // (round 1: per-row partials, 4 DPP steps per value, while they left three workgroups per CU; round 2: wave totals of all band
+  //  groups with one wave_sum4 -- fewer instructions AND a quarter of the LDS, so always)
+  const bool rows = false;
   const size_t sh = (rec_dbl + int_lds_doubles(a.nz, nthr / 64, rows)) * sizeof(double);
   if (sh > 160 * 1024) return CRT_ERR_UNSUPPORTED;
   auto go = [&](auto kern) {

@@ -134,6 +134,7 @@ class BandShardPlan:
                 else:
                     ip = batched.IntegratedPlan(scheme, ct, bt, bw, out=tile.views, **opts)
                     tile.launch = lambda ip=ip: (ip(), None)[1]
+                    tile.kernel_plan = ip
             self.tiles.append(tile)
 
     @staticmethod

@@ -53,4 +53,10 @@ for entry in "${CASES[@]}"; do
   fi
 done
 python3 $R/tools/summarize_profiles.py $OUT > $OUT/summary.json 2> $OUT/summary.err
-echo "done" | tee -a $OUT/progress.log
+# the raw rocprofv3 output is too large to travel back: keep the summary + the trimmed evidence, drop the rest
+SMALL=$R/gpurun_out/prof_${TAG}_small
+rm -rf $SMALL && mkdir -p $SMALL
+python3 $R/tools/summarize_profiles.py $OUT --shrink $SMALL
+cp $OUT/summary.json $OUT/summary.err $OUT/progress.log $SMALL/
+rm -rf $OUT
+echo "done"

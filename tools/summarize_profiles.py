@@ -111,8 +111,37 @@ def traffic_entries(summary, source):
     return ents
 
 
+def shrink(root, dst):
+    """Copy the evidence worth committing (kernel stats, the bench line of the profiled run, the counter rows of this library's
+    kernels) from a raw profile_round.sh directory into `dst` -- the raw rocprofv3 output exceeds what gpurun merges back."""
+    import shutil
+
+    for case in sorted(os.listdir(root)):
+        src = os.path.join(root, case)
+        if not os.path.isdir(src):
+            continue
+        out = os.path.join(dst, case)
+        os.makedirs(out, exist_ok=True)
+        st = find(os.path.join(src, "stats"), "*kernel_stats.csv")
+        if st:
+            shutil.copy(st, os.path.join(out, "kernel_stats.csv"))
+        sj = os.path.join(src, "stats.json")
+        if os.path.exists(sj):
+            lines = [ln for ln in open(sj) if ln.startswith("{")]
+            if lines:
+                open(os.path.join(out, "bench_line.json"), "w").write(lines[0])
+        for c in ("WRITE_SIZE", "FETCH_SIZE", "SQ"):
+            f = find(os.path.join(src, "pmc_" + c), "*counter_collection.csv")
+            if f:
+                rows = open(f).read().splitlines()
+                keep = [rows[0]] + [r for r in rows[1:] if "crt::" in r and "k_fill" not in r and "k_copy" not in r and "k_probe" not in r][:400]
+                open(os.path.join(out, f"pmc_{c}.csv"), "w").write("\n".join(keep) + "\n")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 3 and sys.argv[2] == "--emit-traffic":
+    if len(sys.argv) > 3 and sys.argv[2] == "--shrink":
+        shrink(sys.argv[1], sys.argv[3])
+    elif len(sys.argv) > 3 and sys.argv[2] == "--emit-traffic":
         # usage: summarize_profiles.py <merged summary.json> --emit-traffic <out.json> <source label>
         summ = json.load(open(sys.argv[1]))
         doc = {"_comment": "HBM bytes per launch of each solve kernel from rocprofv3 --pmc (separate passes WRITE_SIZE / FETCH_SIZE of the bench "
