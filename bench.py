@@ -290,6 +290,8 @@ def parse_args(argv):
                     help="process-group backend; 'gloo' + --share-device rehearses the N>1 code path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--launch-check", action="store_true", help="N>1: rendezvous + all-reduce of ones only (no GPU work; CPU test of the launcher)")
+    ap.add_argument("--force-pg", action="store_true", help="create the process group and run every collective even with one rank (RCCL API "
+                    "rehearsal on a one-GPU box: torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 --force-pg)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0)
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     a = ap.parse_args(argv)
@@ -350,7 +352,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    pg = world > 1 or a.force_pg  # collectives in use
+    if pg:
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         else:
@@ -366,12 +369,12 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if pg:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
     def max_over_ranks(x):
-        if world > 1:
+        if pg:
             t = torch.tensor([x], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
@@ -412,7 +415,7 @@ def main():
         bw = torch.as_tensor(spectra.band_weights(d["wle"])).to(dev)
         # --variant integrated: the fused kernel (crt_hip_integrated_f64) forms the band sums without writing any profile
         plan = cdist.BandShardPlan(scheme, cols, bands, bw, column_tiles=a.column_tiles, share_profiles=True, placement=a.placement,
-                                   keep_profiles=a.variant == "profiles")
+                                   keep_profiles=a.variant == "profiles", always_reduce=a.force_pg)
         del bands
         nb_local = plan.band_range[1] - plan.band_range[0]
         res_holder = {}
@@ -429,7 +432,7 @@ def main():
 
         compute_blocks = timed_blocks(compute_only)
         coll_ms, ranks_seen = None, 1
-        if world > 1:
+        if pg:
             ones = torch.ones(1, dtype=torch.float64, device=red_dev)
             dist.all_reduce(ones)
             ranks_seen = int(ones.item())
@@ -442,7 +445,7 @@ def main():
             coll_ms = max_over_ranks((time.perf_counter() - t0) / 5 * 1e3)
         kname = kernel_name(lib)
         knames = [kname]
-        if world > 1:
+        if pg:
             knames = [None] * world
             dist.all_gather_object(knames, (rank, plan.band_range, kname))
         ref = res_holder["r"]["reflectance"]
@@ -482,7 +485,7 @@ def main():
         blocks = timed_blocks(lambda: main_plan())
         solves_per_step = ncol * nb * world
         ncol_kernel, nb_kernel = ncol, nb
-        if world > 1:
+        if pg:
             # RCCL evidence for the scaling runs (outside the timed region, never part of `value`): did the collective see N ranks,
             # and what does the all-reduce of one config-4 column tile's packed sums (2.5e4 x (99 x 9 + 12) doubles = 181 MB) cost here
             ones = torch.ones(1, dtype=torch.float64, device=red_dev)
@@ -499,7 +502,7 @@ def main():
             dist.all_gather_object(knames, (rank, kernel_name(lib)))
             extra["rccl"] = {"backend": "RCCL (nccl)" if a.backend == "nccl" else "gloo (rehearsal)", "ranks_seen": int(ones.item()),
                              "allreduce_ms": ar_ms, "allreduce_bytes": msg.numel() * 8,
-                             "busbw_GBs": 2 * (world - 1) / world * msg.numel() * 8 / (ar_ms * 1e-3) / 1e9, "kernels_per_rank": knames,
+                             "busbw_GBs": 2 * (world - 1) / world * msg.numel() * 8 / (ar_ms * 1e-3) / 1e9 if world > 1 else None, "kernels_per_rank": knames,
                              "note": "measured after the timed region; the column partition has no data-path collective"}
             del msg
 
@@ -664,7 +667,7 @@ def main():
         out["pcie_inclusive"] = pcie
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scheme, nb, nz, a.cpu_budget)
-    if world > 1:
+    if pg:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -95,8 +95,9 @@ class BandShardPlan:
     """
 
     def __init__(self, scheme, cols, bands, band_w, *, group=None, column_tiles=1, keep_profiles=True, share_profiles=False,
-                 solve_fn=None, epilogue_fn=None, integrated_fn=None, placement="auto", **opts):
+                 solve_fn=None, epilogue_fn=None, integrated_fn=None, placement="auto", always_reduce=False, **opts):
         self.scheme, self.group = scheme, group
+        self.always_reduce = always_reduce  # issue the all-reduces even in a world of one rank (API rehearsal)
         self.world, self.rank = _world(group)
         self.ncol, self.nz = cols.ncol, cols.nz
         self.band_range = band_block_range(bands.nb, self.rank, self.world)
@@ -170,7 +171,7 @@ class BandShardPlan:
         for tile in self.tiles:
             tile.profiles = tile.launch()
             tile.work = None
-            if reduce and self.world > 1:
+            if reduce and (self.world > 1 or (self.always_reduce and dist.is_initialized())):
                 # asynchronous: the next tile's kernels are enqueued while this message is on the wire
                 tile.work = dist.all_reduce(tile.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return self
