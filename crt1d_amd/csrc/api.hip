@@ -299,6 +299,116 @@ __global__ __launch_bounds__(256) void k_absorb_bandsum_w(EpiArgs a, int wpb, in
   }
 }
 
+// k_absorb_bandsum_h: very narrow spectra (nb <= 32): a column per HALF wave (lane l of a
+// half owns band l), so a wave instruction serves two columns instead of leaving half of the lanes idle;
+// the reductions stay inside the halves (half_sum2).  Otherwise the same pass.
+template <int NBT, int CH, int NGT>
+__global__ __launch_bounds__(256) void k_absorb_bandsum_h(EpiArgs a, int wpb, int per_col) {
+  extern __shared__ double lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31;
+  const int c0 = 2 * (blockIdx.x * wpb + wave);
+  if (c0 >= a.ncol) return;  // wave-uniform; no workgroup barrier in this kernel
+  const bool colok = c0 + half < a.ncol;
+  const int c = colok ? c0 + half : c0;  // a missing second column repeats the first and writes nothing
+  const int nz = a.nz, nb = a.nb, ng = a.ngroup, nl = nz - 1;
+  double* raw = lds + (size_t)(2 * wave + half) * per_col;  // [nl][NGT][2]
+  double* ends = raw + 2 * NGT * nl;                        // [2][NGT][2]
+  const long long cb = (long long)c * nz * nb;
+  const double* __restrict__ R = a.I_dr + cb;
+  const double* __restrict__ D = a.I_df_d + cb;
+  const double* __restrict__ U = a.I_df_u + cb;
+  int bi[NBT];
+  double w[NBT][NGT], la[NBT], r0[NBT], d0[NBT], u0[NBT];
+#pragma unroll
+  for (int i = 0; i < NBT; ++i) {
+    const int b = l + 32 * i;
+    const bool act = b < nb;
+    bi[i] = act ? b : 0;
+    const long long ib = (long long)c * a.col_stride + bi[i];
+    la[i] = act ? 1 - (a.leaf_r[ib] + a.leaf_t[ib]) : 0.0;  // :584
+#pragma unroll
+    for (int g = 0; g < NGT; ++g) w[i][g] = (g < ng && act) ? a.band_w[(long long)g * nb + bi[i]] : 0.0;
+    r0[i] = R[bi[i]];
+    d0[i] = D[bi[i]];
+    u0[i] = U[bi[i]];
+  }
+  auto end_terms = [&](double* dst) {
+    double v[2 * NGT];
+#pragma unroll
+    for (int g = 0; g < NGT; ++g) {
+      v[2 * g] = v[2 * g + 1] = 0.0;
+#pragma unroll
+      for (int i = 0; i < NBT; ++i) {
+        v[2 * g] += w[i][g] * (r0[i] + d0[i]);
+        v[2 * g + 1] += w[i][g] * u0[i];
+      }
+    }
+    half_sum_store(v, dst, 2 * NGT, lane);
+  };
+  if (a.totals) end_terms(ends);
+  for (int k0 = 0; k0 < nl; k0 += CH) {
+    const int nlev = min(CH, nl - k0);
+    double r1[CH][NBT], d1[CH][NBT], u1[CH][NBT];
+#pragma unroll
+    for (int t = 0; t < CH; ++t)
+      if (t < nlev) {
+        const unsigned row = (unsigned)(k0 + t + 1) * (unsigned)nb;
+#pragma unroll
+        for (int i = 0; i < NBT; ++i) {
+          const unsigned off = row + (unsigned)bi[i];
+          r1[t][i] = __builtin_nontemporal_load(R + off);
+          d1[t][i] = __builtin_nontemporal_load(D + off);
+          u1[t][i] = __builtin_nontemporal_load(U + off);
+        }
+      }
+    double v[CH * NGT * 2];  // [t][g][A, D]
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+#pragma unroll
+      for (int g = 0; g < NGT; ++g) v[(t * NGT + g) * 2] = v[(t * NGT + g) * 2 + 1] = 0.0;
+      if (t < nlev) {
+#pragma unroll
+        for (int i = 0; i < NBT; ++i) {
+          const double av = r1[t][i] - r0[i] + d1[t][i] - d0[i] + u0[i] - u1[t][i];  // :609
+          const double ar = la[i] * r1[t][i];
+#pragma unroll
+          for (int g = 0; g < NGT; ++g) {
+            v[(t * NGT + g) * 2] += w[i][g] * av;
+            v[(t * NGT + g) * 2 + 1] += w[i][g] * ar;
+          }
+          r0[i] = r1[t][i];
+          d0[i] = d1[t][i];
+          u0[i] = u1[t][i];
+        }
+      }
+    }
+    half_sum_store(v, raw + (size_t)k0 * NGT * 2, nlev * NGT * 2, lane);
+  }
+  if (a.totals) end_terms(ends + 2 * NGT);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (!colok) return;
+  const double psi = a.psi[c];
+  const int kind = a.g_kind[c];
+  const double G = (kind == CRT_G_TABLE) ? a.g_at_psi[c] : G_closed(kind, a.g_param ? a.g_param[c] : 0.0, cos(psi), sin(psi));
+  const double Kb = G / cos(psi);
+  const double* __restrict__ lai = a.lai + (long long)c * nz;
+  const long long ob = (long long)c * nl * ng;
+  for (int i = l; i < nl * ng; i += 32) {
+    const int k = i / ng, g = i - k * ng;
+    const double A = raw[(k * NGT + g) * 2], Dg = raw[(k * NGT + g) * 2 + 1];
+    const double fsl = exp(-Kb * ((lai[k] + lai[k + 1]) / 2));       // model.py:601-602
+    const double adr = (1 - exp(-Kb * (lai[k] - lai[k + 1]))) * Dg;  // :617-621
+    const double adf = A - adr;                                      // :628
+    a.aI[ob + i] = A;
+    a.aI_sl[ob + i] = adf * fsl + adr;                               // :631-633
+    a.aI_sh[ob + i] = adf * (1 - fsl);
+  }
+  if (a.totals && l < 4 * ng) {
+    const int g = l >> 2, q = l & 3;
+    a.totals[((long long)c * ng + g) * 4 + q] = ends[(q < 2 ? 2 * NGT : 0) + 2 * g + (q & 1)];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Per-band layer absorption, model.py:573-647: the seven (nz-1, nb) arrays + laim, f_slm of the reference's
 // `Model.absorption` dict.  One workgroup per column, lanes over bands, previous level kept in registers.
@@ -687,6 +797,29 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
   a.aI_sl = aI_sl;
   a.aI_sh = aI_sh;
   a.totals = totals;
+  // measured (tools/epilogue_bench.py): nb = 20: 1.15 ms per wave-column vs 0.85 ms per half-wave-column; nb = 38: 1.11 vs 1.26 (the second band
+  // slot of a half is nearly empty and doubles the per-band work) -> halves only up to 32 bands
+  if (a.nb <= 32 && (long long)a.nz * a.nb < (1ll << 31)) {  // a column per half wave
+    const int nl = a.nz - 1;
+    const int ngt = a.ngroup == 1 ? 1 : a.ngroup <= 3 ? 3 : 4;
+    const int per_col = 2 * ngt * nl + 4 * ngt;
+    int wpb = 4;
+    while (wpb > 1 && (size_t)2 * wpb * per_col * sizeof(double) > 60 * 1024) wpb >>= 1;
+    const size_t shw = (size_t)2 * wpb * per_col * sizeof(double);
+    if (shw <= 64 * 1024) {
+      const dim3 grid((a.ncol + 2 * wpb - 1) / (2 * wpb)), block(64 * wpb);
+      hipStream_t sw = static_cast<hipStream_t>(stream);
+      auto launch = [&](auto ngt_c) {
+        constexpr int NGT = decltype(ngt_c)::value;
+        if (a.nb <= 32) hipLaunchKernelGGL((k_absorb_bandsum_h<1, 4, NGT>), grid, block, shw, sw, a, wpb, per_col);
+        else hipLaunchKernelGGL((k_absorb_bandsum_h<2, 4, NGT>), grid, block, shw, sw, a, wpb, per_col);
+      };
+      if (a.ngroup == 1) launch(std::integral_constant<int, 1>{});
+      else if (a.ngroup <= 3) launch(std::integral_constant<int, 3>{});
+      else launch(std::integral_constant<int, 4>{});
+      return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+    }
+  }
   if (a.nb <= 512 && (long long)a.nz * a.nb < (1ll << 31)) {  // one wave per column
     const int nl = a.nz - 1;
     const int ngt = a.ngroup == 1 ? 1 : a.ngroup <= 3 ? 3 : 4;

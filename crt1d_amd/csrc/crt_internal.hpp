@@ -308,6 +308,21 @@ __device__ inline void wave_sum_store(const double (&v)[N], double* dst, int nva
   }
 }
 
+// TWO per-lane values -> their totals over each HALF of the wave (lanes 0-31 / 32-63), for kernels that give a column to each
+// half: lanes of DPP row 0 end up with sum(x) over the lower half, row 1 with sum(y) over the lower half, rows 2 / 3 the same for the
+// upper half.  3 + 12 = 15 VALU instructions for two values of two columns.
+__device__ inline double half_sum2(double x, double y) { return row_sum16(swap_add16(x, y)); }
+template <int N>
+__device__ inline void half_sum_store(const double (&v)[N], double* dst, int nvalid, int lane) {  // dst: this lane's half's area
+  const int which = (lane >> 4) & 1;
+#pragma unroll
+  for (int j = 0; j < (N + 1) / 2; ++j) {
+    const double z = half_sum2(v[2 * j], 2 * j + 1 < N ? v[2 * j + 1] : 0.0);
+    const int idx = 2 * j + which;
+    if ((lane & 15) == 0 && idx < nvalid) dst[idx] = z;
+  }
+}
+
 __device__ inline double wave_sum_all(double v) {  // sum over the 64 lanes (used once per column only)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -111,12 +111,16 @@ def test_bonan_through_model_and_absorption(oracle):
     assert np.abs(y_sh - g["n79_9sky__aI_lsh"]).mean() < 1e-6
 
 
-def test_epilogue_kernels_vs_oracle(oracle):
+@pytest.mark.parametrize("shape", [(37, 300, 60), (11, 38, 100), (9, 64, 33), (13, 20, 12), (5, 107, 61), (4, 512, 30), (3, 600, 20), (2, 1100, 9), (1, 36, 60)])
+def test_epilogue_kernels_vs_oracle(oracle, shape):
+    """crt_hip_absorb_f64 / crt_hip_absorb_bandsum_f64 on every kernel path: a column per half wave (nb <= 64), per wave (nb <= 512),
+    multi-wave workgroups with band slices (beyond); even nb -> tiled flat walk of the seven per-band outputs, odd nb -> lane per band."""
     import torch
 
     from crt1d_amd import batched, spectra, synth
 
-    d = synth.make_columns(37, 300, 60, seed=8, uniform_dlai=False)
+    ncol, nb, nz = shape
+    d = synth.make_columns(ncol, nb, nz, seed=8, uniform_dlai=False)
     cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
     sol = batched.solve("2s", cols, bands)
     w = spectra.band_weights(d["wle"])
