@@ -231,6 +231,7 @@ int crt_hip_buffer_alloc_set(int32_t n, const size_t* bytes, void** ptrs) {
   // Surplus chunks are released before returning, rarest classes kept.
   size_t free0 = 0, tot0 = 0;
   if (hipMemGetInfo(&free0, &tot0) != hipSuccess) free0 = need * CHUNK + (22ull << 30);
+  free0 += have.size() * CHUNK;  // what the pool already holds counts as available to this request
   const size_t budget = std::min<size_t>(free0 > (6ull << 30) ? free0 - (6ull << 30) : 0, need * CHUNK + (96ull << 30));
   bool oom = false;
   while (!balanced()) {
@@ -246,7 +247,9 @@ int crt_hip_buffer_alloc_set(int32_t n, const size_t* bytes, void** ptrs) {
     if (classify(p, c)) have.push_back(c);
   }
   if (have.size() < need) {
-    p.free_chunks.swap(have);
+    // not enough memory for the request: give everything gathered back to the driver (the caller will fall back to another allocator,
+    // which needs that memory)
+    for (auto& c : have) release_chunk(p, c);
     return oom ? CRT_ERR_WORKSPACE : CRT_ERR_LAUNCH;
   }
   // ---- how many chunks of each class to use: as even as the supply allows
@@ -307,19 +310,21 @@ int crt_hip_buffer_alloc_set(int32_t n, const size_t* bytes, void** ptrs) {
       if (ok) mapped += CHUNK;
     }
     ok = ok && set_access(va, size, dev);
-    if (!ok) {
+    if (!ok) {  // undo everything and hand the memory back: the caller falls back to another allocator
       if (va && mapped) retire_range(va, mapped);
       for (int b = a; b < n; ++b)
-        for (auto& c : per[b]) p.free_chunks.push_back(c);
-      for (int b = 0; b < a; ++b) {  // undo the arrays already built
+        for (auto& c : per[b]) release_chunk(p, c);
+      for (int b = 0; b < a; ++b) {
         auto it = g_buffers.find(ptrs[b]);
         if (it != g_buffers.end()) {
           retire_range(ptrs[b], it->second.size);
-          for (auto& c : it->second.chunks) p.free_chunks.push_back(c);
+          for (auto& c : it->second.chunks) release_chunk(p, c);
           g_buffers.erase(it);
         }
         ptrs[b] = nullptr;
       }
+      for (auto& c : p.free_chunks) release_chunk(p, c);
+      p.free_chunks.clear();
       (void)hipGetLastError();
       return CRT_ERR_WORKSPACE;
     }

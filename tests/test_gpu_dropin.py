@@ -456,6 +456,44 @@ def test_device_buffer_set_lifecycle():
         _lib.check(_lib.load().crt_hip_buffer_free(12345), "crt_hip_buffer_free")
 
 
+def test_buffer_pool_memory_counts_as_available():
+    """Regression (round 2): the chunks of a freed set stay in the per-device pool; a following request larger than what is FREE but
+    smaller than free + pool must succeed (the exploration budget counts the pool's memory), and a request that cannot be met hands
+    everything back instead of sitting on it (the caller falls back to torch.empty, which needs that memory)."""
+    import gc
+
+    import torch
+
+    from crt1d_amd import _lib, batched
+
+    lib = _lib.load()
+    lib.crt_hip_buffer_trim()
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < (120 << 30):
+        pytest.skip("needs 120 GB of free device memory")
+    ballast = torch.empty(free - (64 << 30), dtype=torch.uint8, device="cuda")  # leave 64 GB
+    n8 = lambda gb: (int(gb * (1 << 30)) // 8,)  # noqa: E731
+    a = batched.device_buffers([n8(10)] * 3)       # 30 GB
+    a[0][:16] = 1.0
+    del a
+    gc.collect()                                   # -> 60 chunks in the pool, ~34 GB free
+    assert batched.buffer_stats()["free_chunks"] >= 60
+    b = batched.device_buffers([n8(11)] * 4)       # 44 GB: more than is free, less than free + pool
+    b[3][-16:] = 2.0
+    torch.cuda.synchronize()
+    assert float(b[3][-1]) == 2.0
+    with pytest.raises(RuntimeError):              # 4 x 20 GB cannot fit beside the 44 GB: fails ...
+        batched.device_buffers([n8(20)] * 4)
+    free_after, _ = torch.cuda.mem_get_info()
+    assert free_after >= (64 - 44 - 8) << 30       # ... without keeping what it gathered
+    del b, ballast
+    gc.collect()
+    lib.crt_hip_buffer_trim()
+    torch.cuda.empty_cache()
+
+
 def test_common_tau_functions_vs_reference():
     """Row a7 as public API: tau_b_fn, tau_df_fn ('quad' / '9sky'), K_df_fn of crt1d.solvers.common (golden g9_common.npz from the
     reference).  '9sky' involves no quadrature: 1e-13; 'quad' is bounded by the reference's QUADPACK error (<= 2e-7 here)."""
