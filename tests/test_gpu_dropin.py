@@ -593,3 +593,53 @@ def test_g6_epilogue_ragged_columns():
     for k in ("aI", "aI_sl", "aI_sh"):
         ref = np.einsum("czb,gb->czg", g6[f"ragged2s__{k}"], g6["w_synth"])
         assert np.max(np.abs(res[k].cpu().numpy() - ref)) <= 1e-12 * np.abs(ref).max(), k
+
+
+def test_argument_checks_at_the_python_boundary():
+    """The C ABI takes bare pointers; everything a kernel assumes about caller-supplied arrays is checked before the call
+    (round-1 advisor findings): dtype / shape / device of outputs, profiles, workspace, band_w; missing G tables."""
+    import torch
+
+    from crt1d_amd import batched, spectra, synth
+
+    d = synth.make_columns(6, 40, 12, seed=1)
+    cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
+    w = torch.as_tensor(spectra.band_weights(d["wle"])).cuda()
+    # f32 solve followed by the fp64 epilogue: float profiles read as double would run past the allocation
+    b32 = batched.Bands(*[t.float() for t in (bands.I_dr0, bands.I_df0, bands.leaf_r, bands.leaf_t, bands.soil_r)])
+    s32 = batched.solve("2s", cols, b32)
+    with pytest.raises(TypeError):
+        batched.absorb_bandsum(cols, b32, s32, w)
+    with pytest.raises(TypeError):
+        batched.absorb(cols, bands, s32)  # f64 spectra but f32 profiles
+    sol = batched.solve("n79", cols, bands)
+    with pytest.raises(ValueError):
+        batched.absorb_bandsum(cols, bands, {k: v[:, :-1] for k, v in sol.items()}, w)  # wrong shape (and non-contiguous)
+    with pytest.raises(ValueError):
+        batched.absorb_bandsum(cols, bands, sol, w[:, :-1].contiguous())  # band_w of the wrong width
+    # caller-supplied outputs: n79's mid-level arrays are (ncol, nz-1, nb) -- an (ncol, nz, nb) array in their place is an error
+    out = {k: torch.empty((6, 12, 40), dtype=torch.float64, device="cuda") for k in batched.OUT_KEYS["n79"]}
+    with pytest.raises(ValueError):
+        batched.Plan("n79", cols, bands, out=out)
+    out["aI_lsl"] = torch.empty((6, 11, 40), dtype=torch.float64, device="cuda")
+    out["aI_lsh"] = torch.empty((6, 11, 40), dtype=torch.float64, device="cuda")
+    p = batched.Plan("n79", cols, bands, out=out)
+    p()
+    torch.cuda.synchronize()
+    for k in sol:
+        assert torch.equal(out[k], sol[k]), k
+    with pytest.raises(TypeError):
+        batched.Plan("n79", cols, bands, out={k: v.float() for k, v in out.items()})
+    with pytest.raises(ValueError):
+        batched.Plan("n79", cols, bands, workspace=torch.empty(16, dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        batched.Plan("n79", cols, bands, workspace=torch.empty(1 << 20, dtype=torch.uint8))  # host memory
+    with pytest.raises(ValueError):
+        batched.IntegratedPlan("n79", cols, bands, w, workspace=torch.empty(16, dtype=torch.uint8, device="cuda"))
+    # columns that ask for a sampled G table without bringing one
+    d6 = dict(d, g_kind=np.full(6, 6, dtype=np.int32))
+    c6 = batched.Columns.from_host(d6)
+    with pytest.raises(ValueError):
+        batched.Plan("2s", c6, bands)
+    with pytest.raises(ValueError):
+        batched.absorb_bandsum(c6, bands, batched.solve("2s", cols, bands), w)
