@@ -487,10 +487,10 @@ def main():
         ncol_kernel, nb_kernel = ncol, nb
         if pg:
             # RCCL evidence for the scaling runs (outside the timed region, never part of `value`): did the collective see N ranks,
-            # and what does the all-reduce of one config-4 column tile's packed sums (2.5e4 x (99 x 9 + 12) doubles = 181 MB) cost here
+            # and what does the all-reduce of one config-4 column tile's packed sums (2.5e4 x (99 x 6 + 12) doubles = 121 MB) cost here
             ones = torch.ones(1, dtype=torch.float64, device=red_dev)
             dist.all_reduce(ones)
-            msg = torch.zeros(25000 * (99 * 9 + 12), dtype=torch.float64, device=red_dev)
+            msg = torch.zeros(25000 * (99 * 6 + 12), dtype=torch.float64, device=red_dev)
             dist.all_reduce(msg)
             barrier()
             t0 = time.perf_counter()

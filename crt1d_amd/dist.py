@@ -21,7 +21,11 @@ the HIP path.
 import torch
 import torch.distributed as dist
 
-KEYS = ("aI", "aI_sl", "aI_sh", "totals")  # packed in this order into one message per column tile
+KEYS = ("aI", "aI_sl", "aI_sh", "totals")
+# what travels: aI = aI_sl + aI_sh (model.py:633-635), so the total is NOT sent -- it is re-formed from the reduced sunlit and shaded
+# parts after the all-reduce (a third less on the wire; at 8 ranks the ring all-reduce of config 4's messages is comparable to a
+# rank's compute).  The re-formed sum differs from a directly reduced aI by rounding only (~1e-16 relative).
+MSG_KEYS = ("aI_sl", "aI_sh", "totals")
 
 
 def block_range(n, rank, world, unit=1):
@@ -59,22 +63,22 @@ class _Tile:
     def __init__(self, clo, chi, nz, ng, like):
         self.clo, self.chi = clo, chi
         shapes = _shapes(chi - clo, nz, ng)
-        n = 0
-        for k in KEYS:
+
+        def numel(k):
             m = 1
             for s in shapes[k]:
                 m *= s
-            n += m
-        self.flat = torch.empty(n, dtype=torch.float64, device=like.device)  # the all-reduce message
+            return m
+
+        self.flat = torch.empty(sum(numel(k) for k in MSG_KEYS), dtype=torch.float64, device=like.device)  # the all-reduce message
         self.views, off = {}, 0
-        for k in KEYS:
-            m = 1
-            for s in shapes[k]:
-                m *= s
-            self.views[k] = self.flat[off:off + m].view(shapes[k])
-            off += m
-        self.launch = None   # () -> profiles or None; fills self.flat
+        for k in MSG_KEYS:
+            self.views[k] = self.flat[off:off + numel(k)].view(shapes[k])
+            off += numel(k)
+        self.views["aI"] = torch.empty(shapes["aI"], dtype=torch.float64, device=like.device)  # local; re-formed after a reduce
+        self.launch = None   # () -> profiles or None; fills self.flat and views["aI"]
         self.work = None
+        self.reduced = False
         self.profiles = None
 
 
@@ -171,9 +175,11 @@ class BandShardPlan:
         for tile in self.tiles:
             tile.profiles = tile.launch()
             tile.work = None
+            tile.reduced = False
             if reduce and (self.world > 1 or (self.always_reduce and dist.is_initialized())):
                 # asynchronous: the next tile's kernels are enqueued while this message is on the wire
                 tile.work = dist.all_reduce(tile.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                tile.reduced = self.world > 1
         return self
 
     def wait(self):
@@ -183,6 +189,9 @@ class BandShardPlan:
             if tile.work is not None:
                 tile.work.wait()
                 tile.work = None
+            if tile.reduced:  # the total from its reduced parts (the local aI held this rank's partial sum only)
+                torch.add(tile.views["aI_sl"], tile.views["aI_sh"], out=tile.views["aI"])
+                tile.reduced = False
         if self.ntile == 1:
             res = dict(self.tiles[0].views)
             prof = self.tiles[0].profiles

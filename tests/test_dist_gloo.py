@@ -165,7 +165,7 @@ def test_band_shard_plan_is_reusable_world2():
     solve_fn, epi = _oracle_fns()
     ref = solve_sharded("2s", HostCols(d), HostBands(d), bw, partition="column", solve_fn=solve_fn, epilogue_fn=epi)
     ng = bw.shape[0]
-    nbytes = 8 * (3 * NCOL * (NZ - 1) * ng + NCOL * ng * 4)
+    nbytes = 8 * (2 * NCOL * (NZ - 1) * ng + NCOL * ng * 4)  # aI_sl, aI_sh, totals travel; aI is re-formed after the reduce
     partial = []
     for rank, band_range, msg_bytes, ntile, r1, r2, local_sum in got:
         assert band_range == ((0, 5) if rank == 0 else (5, 9)) and ntile == 3 and msg_bytes == nbytes
