@@ -643,3 +643,39 @@ def test_argument_checks_at_the_python_boundary():
         batched.Plan("2s", c6, bands)
     with pytest.raises(ValueError):
         batched.absorb_bandsum(c6, bands, batched.solve("2s", cols, bands), w)
+
+
+@pytest.mark.parametrize("scheme,shape", [("2s", (200, 300, 60)), ("zq", (60, 300, 100)), ("n79", (40, 107, 60))])
+def test_plan_is_capturable_into_a_hip_graph(scheme, shape):
+    """After the first call on a device (which uploads the quadrature tables) a Plan's launches are stream-only: K0 + solve can be
+    captured into a hipGraph (torch.cuda.CUDAGraph) and replayed, bitwise the same outputs, also after the inputs change in place."""
+    import torch
+
+    from crt1d_amd import batched, synth
+
+    d = synth.make_columns(*shape, seed=3)
+    cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
+    plan = batched.Plan(scheme, cols, bands, placement="none")
+    plan()
+    torch.cuda.synchronize()
+    ref = {k: v.clone() for k, v in plan.out.items()}
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        plan()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        plan()
+    for v in plan.out.values():
+        v.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.equal(plan.out[k], ref[k]), k
+    bands.I_df0.mul_(2.0)  # same buffers, new spectra: the replay reads them through the captured pointers
+    g.replay()
+    torch.cuda.synchronize()
+    fresh = batched.Plan(scheme, cols, bands, placement="none")()
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.equal(plan.out[k], fresh[k]), k
