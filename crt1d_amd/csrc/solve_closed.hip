@@ -745,8 +745,9 @@ constexpr int MAX_DIRECT_LDS = 64 * 1024;
 constexpr int DEFAULT_TILE_LDS = 78 * 1024;
 // Narrow spectra (the 36-38-band shards of an 8-rank band partition): one compute wave + store waves per column beats the
 // direct-store kernel 1.3-1.6x down to 16 bands (tools/ab_narrow.py, 2e5 x 38 x 60: k_direct 4.36 ms, k_pipe 2.67-2.74 ms;
-// 4s: 2.25 -> 1.71 ms with one store wave); below 16 bands the direct kernel keeps its lanes fuller.
-constexpr int MIN_TILE_NB = 16;
+// 4s: 2.25 -> 1.71 ms with one store wave).  Even at 4-15 bands the pipeline with ONE store wave beats the direct kernel, whose 8-byte
+// stores leave partial lines (PMC traffic 1.2 x algorithmic): 4e5 x 12 x 60 3.90 -> 2.77 ms, 6e5 x 6 x 60 6.32 -> 3.54 ms.
+constexpr int MIN_TILE_NB = 4;
 
 int gcd(int x, int y) { return y ? gcd(y, x % y) : x; }
 
@@ -796,7 +797,7 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
     const bool fused = pfused;  // (shadows k_tile's flag inside this block)
     const int pcomp = ((nb + 63) / 64) * 64;
     const size_t plevel = (size_t)S::NARR * nb * sizeof(TIO);
-    int nsw = g_tune[3] > 0 ? g_tune[3] : (pcomp <= 64 && S::HEAVY_INIT ? 1 : pcomp <= 128 ? 2 : 3);
+    int nsw = g_tune[3] > 0 ? g_tune[3] : (pcomp <= 64 && (S::HEAVY_INIT || nb < 16) ? 1 : pcomp <= 128 ? 2 : 3);
     if (pcomp + 64 * nsw > 1024) nsw = (1024 - pcomp) / 64;
     // Two tile buffers of up to 8 levels, line-aligned runs when they fit, at least two workgroups per CU -- and about four
     // for a scheme with a heavy per-band set-up when the spectrum is narrow enough to allow it.  Measured (tools/ab_shapes.py,

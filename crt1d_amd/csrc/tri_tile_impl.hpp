@@ -814,9 +814,11 @@ int launch_pipe(const SolveArgs& a, hipStream_t s, int M, int T, int nsw, bool r
 
 // min_nb: narrow spectra (the 36-38-band shards of an 8-rank band partition) run one compute wave + ONE store wave per column:
 // tools/ab_narrow.py, zq 1e5 x 38 x 100: k_tri_wave 7.54 ms (2.8 TB/s), pipeline with 3 / 2 / 1 store waves 4.5 / 4.2 / 3.74 ms
-// (5.7 TB/s); n79 1e5 x 38 x 60: 4.38 -> 2.13 ms.  Below 16 bands the per-wave kernel keeps its lanes fuller.
+// (5.7 TB/s); n79 1e5 x 38 x 60: 4.38 -> 2.13 ms.  At 10-15 bands the all-waves tile kernel (one wave per column, no store wave) is the
+// best of the three (n79 3e5 x 14 x 60: k_tri_wave 6.73, pipeline 4.29, k_tri_tile 3.88 ms; zq 4e5 x 12 x 60: 6.75 / 6.18 / 5.41);
+// below 10 the per-wave kernel, which packs several columns into a wave, wins again (zq 4e5 x 8 x 60: 3.20 vs 4.81 ms).
 template <class S, typename TIO>
-int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 16) {
+int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 10) {
   done = false;
   const int* g_tri_tune = a.tune + 8;  // this call's overrides (crt_options.tune[8..11])
   if (a.tune[12] > 0) min_nb = a.tune[12];
@@ -858,7 +860,7 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 16
   // With the fused flat flush (round 2; tools/ab_flat.py, 3e4 x 107 x 60: zq 2.25 -> 1.80 ms, n79 1.77 -> 1.61 in k_tri_tile, 1.57 in
   // the pipeline) the narrow pipeline pays for n79 as well.
   const bool flat_ok = a.tune[13] != 1 && flat_flush_ok<S, TIO>(a);
-  if (!fused && g_tri_tune[2] != 1 && g_tri_tune[0] == 0 && ((nthr <= 128 && (S::NOUT == 7 || flat_ok)) || g_tri_tune[2] == 4)) {
+  if (!fused && g_tri_tune[2] != 1 && g_tri_tune[0] == 0 && ((nthr <= 128 && a.nb >= 16 && (S::NOUT == 7 || flat_ok)) || g_tri_tune[2] == 4)) {
     const int nsw = g_tri_tune[3] > 0 ? g_tri_tune[3] : (nthr == 64 ? 1 : 2);
     int st = launch_pipe_generic<S, TIO, 12, 4>(a, s, nsw);
     if (st == CRT_ERR_UNSUPPORTED) st = launch_pipe_generic<S, TIO, 16, 4>(a, s, nsw);
@@ -867,7 +869,7 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 16
       return st;
     }
   }
-  if (fused && g_tri_tune[2] != 1) {  // wave-specialised pipeline first (tune key 10 = 1 disables, key 11 = store waves)
+  if (fused && g_tri_tune[2] != 1 && (a.nb >= 16 || g_tri_tune[2] >= 2)) {  // wave-specialised pipeline first (tune key 10 = 1 disables, key 11 = store waves)
     // Measured on MI355X at 1e4 x 300 (tools/ab_tri.py, profiles/r01/ab_tri_pipe_*.txt; fill probe 6.3-6.8 TB/s):
     //                best k_tri_tile -> double-buffer pipeline (1 WG/CU) -> register-staged pipeline (2 WG/CU)
     //   n79 nz=60 :  1.649 ms        -> 1.522 (M12/T4, 4 store waves)    -> 1.384 (M12/T4, 3 store waves) = 0.93 of the fill rate

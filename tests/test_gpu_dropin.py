@@ -331,7 +331,8 @@ _TRI_PATHS = {"default": {}, "k_tri_tile": {10: 1}, "k_tri_tile M8 T8": {10: 1, 
 
 @pytest.mark.parametrize("scheme", ["2s", "4s", "bl", "g77", "bf", "n79", "zq"])
 @pytest.mark.parametrize("shape", [(23, 300, 60), (9, 107, 61), (6, 64, 13), (5, 128, 60), (3, 600, 33), (4, 255, 100), (7, 300, 7),
-                                   (9, 38, 100), (7, 37, 60), (130, 36, 61), (5, 16, 30), (6, 21, 12)])  # + the narrow band shards
+                                   (9, 38, 100), (7, 37, 60), (130, 36, 61), (5, 16, 30), (6, 21, 12),  # + the narrow band shards
+                                   (40, 12, 60), (33, 6, 20), (21, 11, 33), (50, 4, 9), (17, 14, 100)])  # + very narrow spectra
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_every_kernel_family_gives_the_same_bits(scheme, shape, dtype):
     """The wave-specialised pipelines (double-buffered, register-staged, generic flush), the all-waves tile kernels and the
@@ -359,7 +360,8 @@ def test_every_kernel_family_gives_the_same_bits(scheme, shape, dtype):
         for k in p.out:
             assert bool(torch.isfinite(p.out[k]).all()), (name, k)
             assert torch.equal(p.out[k], ref.out[k]), (name, k)
-    assert len(names) >= 2, names  # the settings really selected different kernels / configurations
+    if nb >= 16:  # (below 10 bands the tridiagonal schemes have the per-wave kernel only, whatever the settings say)
+        assert len(names) >= 2, names  # the settings really selected different kernels / configurations
 
 
 def test_plan_placement_auto():

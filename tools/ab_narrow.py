@@ -12,12 +12,12 @@ cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
 tri = scheme in ("n79", "zq")
 variants = {"default": {}}
 if tri:
-    variants.update({"pipeline (auto)": {12: 16}, "k_tri_tile": {12: 16, 10: 1}, "double-buffer pipe": {12: 16, 10: 2}, "regstage pipe": {12: 16, 10: 3},
-                     "generic pipe": {12: 16, 10: 4}, "pipe M16 T4": {12: 16, 8: 16, 9: 4}, "pipe M8 T4": {12: 16, 8: 8, 9: 4}, "pipe 2 store waves": {12: 16, 11: 2},
-                     "pipe 1 store wave": {12: 16, 11: 1}})
+    variants.update({"pipeline (auto)": {12: 2}, "k_tri_tile": {12: 2, 10: 1}, "double-buffer pipe": {12: 2, 10: 2}, "regstage pipe": {12: 2, 10: 3},
+                     "generic pipe": {12: 2, 10: 4}, "pipe M16 T4": {12: 2, 8: 16, 9: 4}, "pipe M8 T4": {12: 2, 8: 8, 9: 4}, "pipe 2 store waves": {12: 2, 11: 2},
+                     "pipe 1 store wave": {12: 2, 11: 1}})
 else:
-    variants.update({"k_pipe (auto)": {12: 16}, "k_tile CB": {12: 16, 2: 4}, "k_tile CB T=4": {12: 16, 2: 4, 1: 4}, "k_tile CB T=16": {12: 16, 2: 4, 1: 16, 0: 150 * 1024},
-                     "k_pipe 1 store wave": {12: 16, 3: 1}, "k_pipe T=8": {12: 16, 4: 8}, "k_pipe T=16": {12: 16, 4: 16}})
+    variants.update({"k_pipe (auto)": {12: 2}, "k_tile CB": {12: 2, 2: 4}, "k_tile CB T=4": {12: 2, 2: 4, 1: 4}, "k_tile CB T=16": {12: 2, 2: 4, 1: 16, 0: 150 * 1024},
+                     "k_pipe 1 store wave": {12: 2, 3: 1}, "k_pipe T=8": {12: 2, 4: 8}, "k_pipe T=16": {12: 2, 4: 16}})
 plan = batched.Plan(scheme, cols, bands, placement="auto")
 plan(); torch.cuda.synchronize()
 ref = {k: v.clone() for k, v in plan.out.items()}

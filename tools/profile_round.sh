@@ -31,8 +31,9 @@ CASES=(
 "zq_nb107|wfsq|$R/bench.py --scheme zq --nb 107 --ncol 30000 $B"
 "zq_nb38_nz100|wf|$R/bench.py --scheme zq --nb 38 --nz 100 --ncol 100000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
 "2s_nb38|wf|$R/bench.py --scheme 2s --nb 38 --ncol 200000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
-"zq_nb12_wave|wfsq|$R/bench.py --scheme zq --nb 12 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
-"2s_nb12_direct|wf|$R/bench.py --scheme 2s --nb 12 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
+"zq_nb12|wf|$R/bench.py --scheme zq --nb 12 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
+"2s_nb12|wf|$R/bench.py --scheme 2s --nb 12 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
+"zq_nb8_wave|wfsq|$R/bench.py --scheme zq --nb 8 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
 "2s_integrated|wfsq|$R/bench.py --scheme 2s --variant integrated $B"
 "n79_integrated|wfsq|$R/bench.py --scheme n79 --variant integrated $B"
 "zq_integrated|wfsq|$R/bench.py --scheme zq --variant integrated $B"
