@@ -500,10 +500,29 @@ def main():
             ar_ms = max_over_ranks((time.perf_counter() - t0) / 5 * 1e3)
             knames = [None] * world
             dist.all_gather_object(knames, (rank, kernel_name(lib)))
+            # ... and the column partition's own final reduce: grid means of the spectrally integrated absorption / reflectance over the
+            # columns of ALL ranks (crt1d_amd.dist.grid_mean: local sums, one small all-reduce, ratios after it)
+            gm = None
+            if a.variant == "profiles" and not f32:
+                try:
+                    from crt1d_amd import dist as cdist
+                    from crt1d_amd import spectra
+
+                    bwt = torch.as_tensor(spectra.band_weights(d["wle"])).to(dev)
+                    loc = batched.absorb_bandsum(cols, bands, main_plan.out, bwt)
+                    if a.backend != "nccl":
+                        loc = {k: v.cpu() for k, v in loc.items()}
+                    g = cdist.grid_mean(loc, ncol * world)
+                    gm = {"columns": ncol * world, "reflectance_PAR_NIR_solar": [float(x) for x in g["reflectance"]],
+                          "canopy_absorbed_solar_Wm2": float(g["aI"][:, 2].sum()), "message_bytes": int(8 * sum(v[0].numel() for v in loc.values()))}
+                except Exception as e:
+                    print(f"grid-mean reduce failed: {e!r}", file=sys.stderr)
             extra["rccl"] = {"backend": "RCCL (nccl)" if a.backend == "nccl" else "gloo (rehearsal)", "ranks_seen": int(ones.item()),
                              "allreduce_ms": ar_ms, "allreduce_bytes": msg.numel() * 8,
                              "busbw_GBs": 2 * (world - 1) / world * msg.numel() * 8 / (ar_ms * 1e-3) / 1e9 if world > 1 else None, "kernels_per_rank": knames,
-                             "note": "measured after the timed region; the column partition has no data-path collective"}
+                             "grid_mean": gm,
+                             "note": "measured after the timed region; the column partition has no data-path collective in the solve; grid_mean is its final "
+                                     "reduce of the integrated quantities"}
             del msg
 
     blocks_sorted = sorted(blocks)

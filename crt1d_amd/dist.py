@@ -267,6 +267,29 @@ def solve_sharded(scheme, cols, bands, band_w, *, partition="column", group=None
     return res
 
 
+def grid_mean(res, ncol_total, group=None):
+    """Domain means of the integrated results of a COLUMN-partitioned run: every rank sums its own columns' ``aI, aI_sl, aI_sh
+    (ncol_local, nz-1, ngroup)`` and ``totals (ncol_local, ngroup, 4)``, ONE small all-reduce (RCCL) adds the ranks' sums, and the
+    means and the grid reflectance (reflected / incoming, ``diagnostics.py:510-511``) are formed after it -- "the final reduce of
+    spectrally-integrated absorption / reflectance" of the column partition.  Every rank gets the same result."""
+    keys = ("aI", "aI_sl", "aI_sh", "totals")
+    flat = torch.cat([res[k].sum(dim=0).reshape(-1) for k in keys])
+    world, _ = _world(group)
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat = flat / float(ncol_total)
+    out, off = {}, 0
+    for k in keys:
+        shape = res[k].shape[1:]
+        n = 1
+        for x in shape:
+            n *= x
+        out[k] = flat[off:off + n].view(shape)
+        off += n
+    out["reflectance"] = out["totals"][..., 1] / out["totals"][..., 0]
+    return out
+
+
 def gather_columns(local, ncol, group=None):
     """All-gather per-column integrated results of a column-partitioned run into full ``(ncol, ...)`` tensors."""
     world, _ = _world(group)

@@ -195,3 +195,44 @@ def test_bench_launcher_spawns_ranks_itself():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--partition", "nonsense"],
                          capture_output=True, text=True, timeout=120, env=env)
     assert bad.returncode != 0
+
+
+def _gm_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from crt1d_amd.dist import grid_mean, solve_sharded
+
+        d, bw = _problem()
+        solve_fn, epi = _oracle_fns()
+        rc = solve_sharded("2s", HostCols(d), HostBands(d), bw, partition="column", solve_fn=solve_fn, epilogue_fn=epi)
+        g = grid_mean(rc, NCOL)
+        q.put((rank, {k: v.numpy().copy() for k, v in g.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grid_mean_of_the_column_partition_world2():
+    """The column partition's final reduce: grid means of the integrated absorption / reflectance over the columns of all ranks."""
+    from crt1d_amd.dist import solve_sharded
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d, bw = _problem()
+    solve_fn, epi = _oracle_fns()
+    ref = solve_sharded("2s", HostCols(d), HostBands(d), bw, partition="column", solve_fn=solve_fn, epilogue_fn=epi)  # world of one
+    for _, g in got:
+        for k in ("aI", "aI_sl", "aI_sh", "totals"):
+            np.testing.assert_allclose(g[k], ref[k].numpy().mean(axis=0), rtol=1e-12, atol=1e-14)
+        tot = ref["totals"].numpy().sum(axis=0)
+        np.testing.assert_allclose(g["reflectance"], tot[:, 1] / tot[:, 0], rtol=1e-12)
+    for k in got[0][1]:
+        np.testing.assert_array_equal(got[0][1][k], got[1][1][k])
