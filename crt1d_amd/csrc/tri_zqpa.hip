@@ -165,7 +165,7 @@ __global__ __launch_bounds__(MAXT) void k_zqpa_pipe(SolveArgs a, PipeCfg cfg) {
 // returns CRT_ERR_UNSUPPORTED when the shape does not fit (caller falls back to the two-kernel path)
 template <typename TIO, int M, int T>
 int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
-  if (a.nb % 2 || a.nb < 64) return CRT_ERR_UNSUPPORTED;
+  if (a.nb % 2 || a.nb < (a.tune[12] > 0 ? a.tune[12] : 16)) return CRT_ERR_UNSUPPORTED;  // (tune 12: smallest nb, as for the other pipelines)
   for (int i = 0; i < 4; ++i)
     if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) return CRT_ERR_UNSUPPORTED;
   const int Mg = zqpa_M(a.nz);
@@ -174,7 +174,7 @@ int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
   //   1e4 x 300 x 60: 3.16 ms -> 1.51 / 1.34 / 1.67 / 1.60;  6e3 x 300 x 100 (one workgroup per CU): 3.16 -> 1.88 / 1.70 / 1.61 / 1.56;
   //   3e4 x 128 x 60: 3.47 -> 1.56 / 2.26 / 2.26 / 2.15
   const size_t lds_doubles = (size_t)((a.reclen + 1) & ~1) + ((a.nb + 1) & ~1) + 2 * (size_t)(Mg / M + 1) * ncomp + 4 * (size_t)T * a.nb + 6 * (size_t)a.nb;
-  if (nsw <= 0) nsw = ncomp <= 128 ? 2 : (lds_doubles * sizeof(double) > MAX_WG_LDS / 2 ? 5 : 3);
+  if (nsw <= 0) nsw = ncomp <= 64 ? 1 : ncomp <= 128 ? 2 : (lds_doubles * sizeof(double) > MAX_WG_LDS / 2 ? 5 : 3);
   if (ncomp + 64 * nsw > 1024) nsw = (1024 - ncomp) / 64;
   if (nsw < 1) return CRT_ERR_UNSUPPORTED;
   const int nthr = ncomp + 64 * nsw;
