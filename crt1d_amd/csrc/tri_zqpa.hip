@@ -147,7 +147,123 @@ __device__ __forceinline__ void zqpa_pipe_store(const SolveArgs& a, const PipeCf
   }
 }
 
-template <typename TIO, int M, int T, int MAXT>
+// Odd nb: the same store role as a flat walk over the run's (jhi - jlo) * nb elements (rows are not pair-aligned), element pairs
+// on the pair grid of the arrays (as flush_flat_class does for the other schemes), the unpaired ends by one thread.  Scalar
+// forms of the same expressions -> bitwise the same profiles.
+template <typename TIO, int M, int T>
+__device__ __forceinline__ void zqpa_pipe_store_flat(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
+  typedef TIO vt __attribute__((ext_vector_type(2)));
+  static_assert(T >= 2, "the halo holds the two lowest rows of a tile");
+  const int nb = a.nb, Mg = a.nz, nzo = cfg.nz_out;
+  const int c = blockIdx.x;
+  const int sid = threadIdx.x - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
+  const double* rec = lds;
+  const double invmu = rec[S_INVMU];
+  const double* ekl = rec + REC_HDR + nzo;
+  const double* kidx = ekl + nzo;
+  const double* wgt = kidx + nzo;
+  const double* bandc = lds + cfg.off_bc;
+  const double* tile = lds + cfg.off_tile;  // [2 buffers][dn, up][T][nb]
+  double* halo = lds + cfg.off_halo;        // [2 parities][dn(ktop), up(ktop), up(ktop+1)][nb]
+  TIO* const o0 = outp<TIO>(cfg.out[0]);
+  TIO* const o1 = outp<TIO>(cfg.out[1]);
+  TIO* const o2 = outp<TIO>(cfg.out[2]);
+  TIO* const o3 = outp<TIO>(cfg.out[3]);
+  const int K = Mg + 1;
+  const int step = 2 * nst, dt = step / nb, db = step - dt * nb;
+  int buf = 0, g = 0, jhi = nzo;
+  for (int seg = (K - 1) / M; seg >= 0; --seg) {
+    const int k0 = seg * M;
+    const int kend = min(k0 + M - 1, K - 1);
+    for (int i = M - T; i >= 0; i -= T) {
+      const int k = k0 + i;
+      if (k > kend) continue;
+      lds_barrier();
+      const int ktop = min(k + T, kend + 1);
+      int jlo = 0;
+      if (k > 0) {
+        int lo = 0, hi = jhi;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if ((int)kidx[mid] >= k + 2)
+            hi = mid;
+          else
+            lo = mid + 1;
+        }
+        jlo = lo;
+      }
+      const double* cur = tile + (size_t)buf * (2 * T * nb);
+      const double* hal = halo + (size_t)((g + 1) & 1) * (3 * nb);
+      auto row = [&](int q, int r, int b) -> double {
+        return r < ktop ? cur[(q * T + (r - k)) * nb + b] : hal[(q + (r - ktop)) * nb + b];
+      };
+      auto elem = [&](int j, int b, double& idr, double& dn, double& up) {
+        const int ka = (int)kidx[j];
+        const double w = wgt[j];
+        const double da = row(0, ka - 1, b), db_ = row(0, max(ka - 2, 0), b);
+        const double ua = row(1, min(ka, Mg - 1), b), ub = row(1, ka - 1, b);
+        dn = da + (db_ - da) * w;  // :360
+        up = ua + (ub - ua) * w;   // :361
+        idr = bandc[b] * ekl[j];   // :354-355
+      };
+      const int n = (jhi - jlo) * nb;
+      const long long g0 = ((long long)c * nzo + jlo) * nb;
+      if (n > 0) {
+        const int mis = (int)(g0 & 1);
+        const int npair = (n - mis) >> 1;
+        int e = mis + 2 * sid;
+        int t = (int)(((float)e + 0.5f) * (1.0f / (float)nb));
+        int b = e - t * nb;
+        if (b < 0) { --t; b += nb; }
+        if (b >= nb) { ++t; b -= nb; }
+        for (int idx = sid; idx < npair; idx += nst) {
+          const bool wrap = b + 1 >= nb;
+          const int t2 = wrap ? t + 1 : t, b2 = wrap ? 0 : b + 1;
+          double ix, dx, ux, iy, dy, uy;
+          elem(jlo + t, b, ix, dx, ux);
+          elem(jlo + t2, b2, iy, dy, uy);
+          vt v;
+          v.x = (TIO)ix, v.y = (TIO)iy;
+          *reinterpret_cast<vt*>(o0 + g0 + e) = v;
+          v.x = (TIO)dx, v.y = (TIO)dy;
+          *reinterpret_cast<vt*>(o1 + g0 + e) = v;
+          v.x = (TIO)ux, v.y = (TIO)uy;
+          *reinterpret_cast<vt*>(o2 + g0 + e) = v;
+          v.x = (TIO)(ix * invmu + 2 * ux + 2 * dx), v.y = (TIO)(iy * invmu + 2 * uy + 2 * dy);  // :412
+          *reinterpret_cast<vt*>(o3 + g0 + e) = v;
+          e += step;
+          b += db;
+          t += dt;
+          if (b >= nb) {
+            b -= nb;
+            ++t;
+          }
+        }
+        if (sid == 0) {
+          auto single = [&](int el, int j, int b) {
+            double ix, dx, ux;
+            elem(j, b, ix, dx, ux);
+            o0[g0 + el] = (TIO)ix;
+            o1[g0 + el] = (TIO)dx;
+            o2[g0 + el] = (TIO)ux;
+            o3[g0 + el] = (TIO)(ix * invmu + 2 * ux + 2 * dx);
+          };
+          if (mis) single(0, jlo, 0);
+          if ((n - mis) & 1) single(n - 1, jhi - 1, nb - 1);
+        }
+      }
+      if (ktop - k >= 2) {
+        double* hw = halo + (size_t)(g & 1) * (3 * nb);
+        for (int idx = sid; idx < 3 * nb; idx += nst) hw[idx] = idx < nb ? cur[idx] : cur[(T - 1) * nb + idx];
+      }
+      jhi = jlo;
+      buf ^= 1;
+      ++g;
+    }
+  }
+}
+
+template <typename TIO, int M, int T, int MAXT, bool FLAT>
 __global__ __launch_bounds__(MAXT) void k_zqpa_pipe(SolveArgs a, PipeCfg cfg) {
   extern __shared__ double lds[];
   {
@@ -156,7 +272,10 @@ __global__ __launch_bounds__(MAXT) void k_zqpa_pipe(SolveArgs a, PipeCfg cfg) {
   }
   __syncthreads();
   if ((int)threadIdx.x >= cfg.ncomp) {
-    zqpa_pipe_store<TIO, M, T>(a, cfg, lds);
+    if constexpr (FLAT)
+      zqpa_pipe_store_flat<TIO, M, T>(a, cfg, lds);
+    else
+      zqpa_pipe_store<TIO, M, T>(a, cfg, lds);
     return;
   }
   tri_pipe_compute<TriZqPa, TIO, M, T, 0, 2>(a, cfg, lds);
@@ -165,7 +284,9 @@ __global__ __launch_bounds__(MAXT) void k_zqpa_pipe(SolveArgs a, PipeCfg cfg) {
 // returns CRT_ERR_UNSUPPORTED when the shape does not fit (caller falls back to the two-kernel path)
 template <typename TIO, int M, int T>
 int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
-  if (a.nb % 2 || a.nb < (a.tune[12] > 0 ? a.tune[12] : 16)) return CRT_ERR_UNSUPPORTED;  // (tune 12: smallest nb, as for the other pipelines)
+  if (a.nb < (a.tune[12] > 0 ? a.tune[12] : 16)) return CRT_ERR_UNSUPPORTED;  // (tune 12: smallest nb, as for the other pipelines)
+  const bool flat = a.nb % 2;  // odd nb: rows are not pair-aligned -> flat store role
+  if (flat && a.tune[13] == 1) return CRT_ERR_UNSUPPORTED;
   for (int i = 0; i < 4; ++i)
     if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) return CRT_ERR_UNSUPPORTED;
   const int Mg = zqpa_M(a.nz);
@@ -197,10 +318,11 @@ int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, g, cfg);
-    note_kernel("k_zqpa_pipe<%s> M=%d T=%d store_waves=%d lds=%zu", sizeof(TIO) == 8 ? "f64" : "f32", M, T, nsw, sh);
+    note_kernel("k_zqpa_pipe<%s%s> M=%d T=%d store_waves=%d lds=%zu", sizeof(TIO) == 8 ? "f64" : "f32", flat ? ",flat" : "", M, T, nsw, sh);
     return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
   };
-  return nthr <= 512 ? go(k_zqpa_pipe<TIO, M, T, 512>) : go(k_zqpa_pipe<TIO, M, T, 1024>);
+  if (flat) return nthr <= 512 ? go(k_zqpa_pipe<TIO, M, T, 512, true>) : go(k_zqpa_pipe<TIO, M, T, 1024, true>);
+  return nthr <= 512 ? go(k_zqpa_pipe<TIO, M, T, 512, false>) : go(k_zqpa_pipe<TIO, M, T, 1024, false>);
 }
 
 }  // namespace

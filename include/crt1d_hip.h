@@ -187,8 +187,8 @@ int crt_hip_zq_f32(const crt_columns*, const crt_bands_f32*, const crt_options*,
 int crt_hip_bl_f32(const crt_columns*, const crt_bands_f32*, const crt_options*, const crt_outputs_f32*, void*, size_t, crt_stream_t);
 int crt_hip_g77_f32(const crt_columns*, const crt_bands_f32*, const crt_options*, const crt_outputs_f32*, void*, size_t, crt_stream_t);
 int crt_hip_bf_f32(const crt_columns*, const crt_bands_f32*, const crt_options*, const crt_outputs_f32*, void*, size_t, crt_stream_t);
-/* zq_pa with f32 storage runs in the single-kernel form only: even nb, 16 <= nb <= 832, else CRT_ERR_UNSUPPORTED (this excludes the
- * reference's default 107 bands: use crt_hip_zq_pa_f64 there) */
+/* zq_pa with f32 storage runs in the single-kernel form only: 16 <= nb <= 832 (even or odd: the reference's default 107 bands are
+ * covered), else CRT_ERR_UNSUPPORTED */
 int crt_hip_zq_pa_f32(const crt_columns*, const crt_bands_f32*, const crt_options*, const crt_outputs_f32*, void*, size_t, crt_stream_t);
 
 /*

@@ -204,7 +204,7 @@ def test_f32_storage_variant(scheme, shape):
     cols = batched.Columns.from_host(d)
     b32 = batched.Bands.from_host({k: (d[k].astype(np.float32) if k in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r") else d[k]) for k in d})
     assert b32.dtype == torch.float32
-    if scheme == "zq_pa" and (nb % 2 or nb < 16 or nb > 832):  # f32 zq_pa exists in the single-kernel form only (even nb >= 16)
+    if scheme == "zq_pa" and (nb < 16 or nb > 832):  # f32 zq_pa exists in the single-kernel form only (16 <= nb, LDS-limited above)
         with pytest.raises(RuntimeError, match="not supported"):
             batched.solve(scheme, cols, b32)
         return
@@ -522,7 +522,8 @@ def test_common_tau_functions_vs_reference():
 
 
 @pytest.mark.parametrize("shape", [(23, 300, 60), (130, 64, 13), (5, 600, 33), (4, 128, 150), (3, 300, 250), (6, 300, 3), (5, 300, 2), (7, 96, 101),
-                                   (9, 38, 100), (11, 16, 30), (6, 36, 130), (8, 62, 61)])
+                                   (9, 38, 100), (11, 16, 30), (6, 36, 130), (8, 62, 61),
+                                   (9, 107, 60), (7, 107, 61), (5, 299, 100), (4, 17, 33), (3, 65, 150), (5, 129, 2), (2, 601, 40), (6, 63, 101)])
 @pytest.mark.parametrize("uniform", [True, False])
 def test_zq_pa_fused_interpolation_equals_two_kernel_path(shape, uniform):
     """zq_pa in one kernel (the store waves interpolate from the computational grid to the caller's levels; no workspace scratch) must be
@@ -544,6 +545,7 @@ def test_zq_pa_fused_interpolation_equals_two_kernel_path(shape, uniform):
             v.fill_(float("nan"))
         p()
         torch.cuda.synchronize()
+        assert "k_zqpa_pipe" in p.last_kernel() and ("flat" in p.last_kernel()) == bool(shape[1] % 2)
         for k in ref.out:
             assert torch.equal(p.out[k], ref.out[k]), (k, nsw)
 
