@@ -10,159 +10,129 @@ Multi-column use (the reference's ``run_sensitivity`` is a ``NotImplementedError
 :func:`run_columns` solves many independent canopies in one launch.
 """
 
+import copy
+import pprint
+import traceback
 import warnings
-from collections import namedtuple
-from copy import deepcopy
 
 import numpy as np
 
+from . import canopy
+from .canopy import CANOPY_DESCRIPTION_KEYS, CanopyDescription
 from .cases import load_default_case
 from .solvers import AVAILABLE_SCHEMES, RET_KEYS_ALL_SCHEMES
-from .solvers.common import KbFunction
 from .variables import VMD
 
 __all__ = ("Model", "Dataset", "run_columns")
 
-CANOPY_DESCRIPTION_KEYS = [
-    "lai", "z", "dlai", "lai_tot", "lai_eff", "mla", "clump", "leaf_t", "leaf_r", "soil_r", "wl_leafsoil", "orient", "G_fn",
-]
-CanopyDescription = namedtuple("CanopyDescription", " ".join(CANOPY_DESCRIPTION_KEYS))
+_FALLBACK_SCHEME = "2s"
+_SOLUTION_VARS = ("I_dr", "I_df_d", "I_df_u", "F")
+_SCHEME_SUFFIX = "_scheme"
 
 
 class Model:
-    """A general class for testing 1-D canopy radiative transfer schemes (GPU-backed)."""
+    """One canopy, one scheme: holds the case, runs the scheme's solver on the GPU, keeps the results.
 
-    required_input_keys = tuple(
-        [k for k in CANOPY_DESCRIPTION_KEYS if k not in ("dlai", "lai_tot", "lai_eff")]
-        + ["I_dr0_all", "I_df0_all", "wl", "dwl", "psi"]
-    )
+    State: ``_p`` (inputs + what :func:`crt1d_amd.canopy.derive` adds), ``scheme`` (registry entry), ``out`` (the four contract
+    profiles), ``out_extra`` (everything else the scheme returned, keys suffixed ``_scheme``), ``absorption``."""
+
+    required_input_keys = canopy.INPUT_KEYS
     _schemes = AVAILABLE_SCHEMES
     vmd = VMD
 
     def __init__(self, scheme="2s", nlayers=60, **p_kwargs):
         self.nlayers = nlayers
-        self.p_default = load_default_case(nlayers=self.nlayers)
-        self._p = deepcopy(self.p_default)
+        self.p_default = load_default_case(nlayers=nlayers)
+        self._p = copy.deepcopy(self.p_default)
+        self._run_count = 0
+        self.out, self.out_extra, self.absorption = {}, {}, None
         self.assign_scheme(scheme)
+        self._check_inputs()  # the default case; a failing update below then has something valid to fall back to
         if p_kwargs:
             self.update_p(**p_kwargs)
-        else:
-            self._check_inputs()
-        self._run_count = 0
-        self.absorption = None
-        self.out = {}
-        self.out_extra = {}
 
-    # ---- parameters -------------------------------------------------------------------------
+    # ---- the case ---------------------------------------------------------------------------
     @property
     def p(self):
-        print(
-            "Please update parameters using `.update_p()`! Changes to `.p` will not be stored!\n"
-            "Extract (copy) the parameters using `.copy_p()` or summarize using `.print_p()`."
-        )
-
-    def print_p(self):
-        import pprint
-
-        with np.printoptions(precision=3, threshold=7):
-            pprint.PrettyPrinter(indent=1).pprint(self._p)
+        """Not the parameters: a reminder (the reference does the same, ``model.py:108-116``), since edits to a returned dict
+        would bypass validation."""
+        print("Please update parameters using `.update_p()`! Changes to `.p` will not be stored!\n"
+              "Extract (copy) the parameters using `.copy_p()` or summarize using `.print_p()`.")
 
     def copy_p(self):
-        return deepcopy(self._p)
+        return copy.deepcopy(self._p)
+
+    def print_p(self):
+        with np.printoptions(precision=3, threshold=7):
+            pprint.pprint(self._p, indent=1)
 
     @property
     def cd(self):
-        return CanopyDescription(**{k: v for k, v in self._p.items() if k in CANOPY_DESCRIPTION_KEYS})
+        return CanopyDescription(*(self._p[k] for k in CANOPY_DESCRIPTION_KEYS))
 
     def __repr__(self):
         return f"Model(scheme={self.scheme['name']!r}, psi={self._p['psi']:.4g})"
 
     def assign_scheme(self, scheme_name, *, verbose=False):
-        """Unknown names print a message and fall back to '2s', as the reference (``model.py:157-168``)."""
-        try:
-            self.scheme = AVAILABLE_SCHEMES[scheme_name]
-            if verbose:
-                print("\n\n" + "=" * 40 + f"\nscheme: {self.scheme['name']}\n" + "-" * 40)
-        except KeyError:
-            print(f"{scheme_name!r} is not a valid scheme name/ID!")
-            print(f"The valid ones are: {', '.join(AVAILABLE_SCHEMES)}.")
-            print("Defaulting to Dickinson-Sellers two-stream.\n")
-            self.scheme = AVAILABLE_SCHEMES["2s"]
+        """Select a registered scheme by ID.  An unknown ID is reported on stdout and replaced by '2s' (``model.py:157-168``)."""
+        entry = AVAILABLE_SCHEMES.get(scheme_name)
+        if entry is None:
+            print(f"{scheme_name!r} is not a valid scheme name/ID!\nThe valid ones are: {', '.join(AVAILABLE_SCHEMES)}.\n"
+                  "Defaulting to Dickinson-Sellers two-stream.\n")
+            entry = AVAILABLE_SCHEMES[_FALLBACK_SCHEME]
+        elif verbose:
+            rule = "=" * 40
+            print(f"\n\n{rule}\nscheme: {entry['name']}\n{'-' * 40}")
+        self.scheme = entry
         return self
 
     def update_p(self, **kwargs):
-        """Update parameters if validation passes; on any failure warn and revert (``model.py:173-203``)."""
-        import traceback
-
-        p0 = deepcopy(self._p)
+        """Replace inputs.  All-or-nothing: the candidate case is validated as a whole and adopted only if that succeeds, otherwise
+        a warning carries the traceback and the previous case stays (``model.py:173-203``).  Non-input keys are skipped with a
+        warning."""
+        accepted = {}
+        for name, value in kwargs.items():
+            if name in canopy.INPUT_KEYS:
+                accepted[name] = value
+            else:
+                warnings.warn(f"{name!r} is not intended as an input and will be ignored")
+        candidate = {**self._p, **accepted}
         try:
-            for k, v in kwargs.items():
-                if k not in Model.required_input_keys:
-                    warnings.warn(f"{k!r} is not intended as an input and will be ignored")
-                    continue
-                self._p[k] = v
-            self._check_inputs()
+            candidate.update(canopy.derive(candidate))
         except Exception:
             warnings.warn(f"Updating parameters failed. Full traceback:\n\n{traceback.format_exc()}\nReverting.")
-            self._p = p0
+        else:
+            self._adopt(candidate)
         return self
 
     def update_spectra(self, ds):
-        """From any mapping with ``I_dr, I_df, wl, dwl, tl, rl, rs`` (an ``xarray.Dataset`` in the reference)."""
-        g = lambda k: np.asarray(getattr(ds[k], "values", ds[k]))  # noqa: E731
-        self.update_p(I_dr0_all=g("I_dr"), I_df0_all=g("I_df"), wl=g("wl"), dwl=g("dwl"), leaf_t=g("tl"), leaf_r=g("rl"),
-                      soil_r=g("rs"), wl_leafsoil=g("wl"))
-        return self
+        """Inputs from a spectra container with ``I_dr, I_df, wl, dwl, tl, rl, rs`` (an ``xarray.Dataset`` in the reference, any
+        mapping of arrays here)."""
+        take = lambda k: np.asarray(getattr(ds[k], "values", ds[k]))  # noqa: E731
+        renamed = {"I_dr0_all": "I_dr", "I_df0_all": "I_df", "wl": "wl", "dwl": "dwl", "leaf_t": "tl", "leaf_r": "rl", "soil_r": "rs",
+                   "wl_leafsoil": "wl"}
+        return self.update_p(**{ours: take(theirs) for ours, theirs in renamed.items()})
+
+    def _adopt(self, case):
+        self._p = case
+        self.nlev, self.nwl = canopy.sizes(case)
 
     def _check_inputs(self):
-        """Derive ``lai_tot, lai_eff, dlai, zm, dz, mu, wle, K_b_fn, G, K_b`` and validate (``model.py:222-294``)."""
-        p = self._p
-        for key in Model.required_input_keys:
-            if key not in p:
-                raise Exception(f"required key {key} is not present. Set it using `update_p`.")
-        lai = np.asarray(p["lai"], dtype=float)
-        z = np.asarray(p["z"], dtype=float)
-        dz = np.diff(z)
-        assert z.size == lai.size
-        self.nlev = lai.size
-        assert z[-1] > z[0]  # z increasing
-        assert lai[0] > lai[-1]  # LAI decreasing
-        assert lai[-1] == 0
-        p["lai_tot"] = lai[0]
-        p["lai_eff"] = lai * p["clump"]
-        dlai = lai[:-1] - lai[1:]
-        p["dlai"] = dlai
-        p["dlai_eff"] = dlai * p["clump"]
-        p["zm"] = z[:-1] + 0.5 * dz
-        p["dz"] = dz
-        psi = p["psi"]
-        if "mu" in p:
-            if p["mu"] != np.cos(psi):
-                warnings.warn("Provided `mu` not consistent with provided `psi`. `mu` will be updated based on the value of `psi`.")
-        p["mu"] = np.cos(psi)
-        wl_toc, wl_op = np.asarray(p["wl"]), np.asarray(p["wl_leafsoil"])
-        assert wl_toc.size == wl_op.size
-        if not np.allclose(wl_toc, wl_op):
-            warnings.warn(
-                "Provided wavelengths for optical props (`wl_leafsoil`) and toc BC (`wl`) appear to be incompatible:\n"
-                f"`wl - wl_leafsoil`:\n{wl_toc - wl_op}"
-            )
-        self.nwl = wl_toc.size
-        assert np.asarray(p["wl"]).size == np.asarray(p["dwl"]).size
-        p["wle"] = np.r_[p["wl"][0] - 0.5 * p["dwl"][0], np.asarray(p["wl"]) + 0.5 * np.asarray(p["dwl"])]
-        p["K_b_fn"] = KbFunction(p["G_fn"])  # lambda psi_: G_fn(psi_) / cos(psi_), model.py:291
-        p["G"] = p["G_fn"](psi)
-        p["K_b"] = p["K_b_fn"](psi)
+        """(Re)derive ``lai_tot, lai_eff, dlai, zm, dz, mu, wle, K_b_fn, G, K_b`` from the inputs; raises on an unsolvable case
+        (``model.py:222-294``)."""
+        self._adopt({**self._p, **canopy.derive(self._p)})
 
-    # ---- run --------------------------------------------------------------------------------
+    # ---- solve ------------------------------------------------------------------------------
     def run(self, **extra_solver_kwargs):
+        """Call the scheme's solver with the arguments its signature names (``model.py:296-320``)."""
         self._check_inputs()
-        scheme = self.scheme
-        p = self._p
-        args = {k: p[k] for k in scheme["args"]}
-        sol = scheme["solver"](**args, **extra_solver_kwargs)
-        self.out.update({k: v for k, v in sol.items() if k in RET_KEYS_ALL_SCHEMES})
-        self.out_extra.update({f"{k}_scheme": v for k, v in sol.items() if k not in RET_KEYS_ALL_SCHEMES})
+        solver, argnames = self.scheme["solver"], self.scheme["args"]
+        returned = solver(**{name: self._p[name] for name in argnames}, **extra_solver_kwargs)
+        for name, value in returned.items():
+            if name in RET_KEYS_ALL_SCHEMES:
+                self.out[name] = value
+            else:
+                self.out_extra[name + _SCHEME_SUFFIX] = value
         self._run_count += 1
         return self
 
@@ -170,10 +140,13 @@ class Model:
     def out_all(self):
         return {**self.out, **self.out_extra}
 
+    def _need_run(self, purpose):
+        if not self._run_count:
+            raise Exception(f"Must run the model {purpose}.")
+
     def calc_absorption(self):
         """Layerwise absorption (``model.py:573-647``), computed by the device epilogue kernel."""
-        if self._run_count == 0:
-            raise Exception("Must run the model first.")
+        self._need_run("first")
         import torch
 
         from . import batched
@@ -192,55 +165,48 @@ class Model:
         sol = {k: t(self.out[k])[None] for k in ("I_dr", "I_df_d", "I_df_u")}
         res = batched.absorb(cols, bands, sol)
         ab = {k: v[0].cpu().numpy() for k, v in res.items()}
-        ab["f_slm"] = ab.pop("f_slm")
-        assert np.allclose(ab["aI_sl"] + ab["aI_sh"], ab["aI"])  # sanity check, model.py:635
+        if not np.allclose(ab["aI_sl"] + ab["aI_sh"], ab["aI"]):  # the reference's sanity check, model.py:635
+            raise AssertionError("sunlit + shaded absorption does not add up to the total")
         self.absorption = ab
         return self
+
+    # ---- output container -------------------------------------------------------------------
+    def _scheme_absorption_vars(self, nz):
+        """The scheme's own absorption outputs (``aI*_scheme``): on levels or on layers, by their leading size."""
+        from .variables import da_attrs
+
+        for name, arr in self.out_extra.items():
+            if not name.startswith("aI"):
+                continue
+            dims = {nz: ("z", "wl"), nz - 1: ("zm", "wl")}.get(arr.shape[0])
+            if dims is None:
+                raise ValueError("Scheme absorption output has too many or too few levels.")
+            base = name[: -len(_SCHEME_SUFFIX)]
+            try:
+                yield name, (dims, arr, da_attrs(base))
+            except KeyError:
+                raise Exception(f"Scheme absorbance variable {base} not found in vmd.") from None
 
     def to_dataset(self, *, info=""):
         """The reference's output dataset (``model.py:338-447``) as a plain :class:`Dataset`: same coordinates (``z, wl, zm,
         wle``), data variables (solution, ``I_d``, grid, absorption, scheme extras named ``aI*_scheme``, geometry scalars),
         dims, attributes and global attributes.  No xarray needed; :meth:`to_xr` converts when it is installed."""
         from . import __version__
-        from .variables import da_attrs, dv_tuple
+        from .variables import dv_tuple
 
-        if self._run_count == 0:
-            raise Exception("Must run the model before creating the dataset.")
-        p = self._p
-        out = self.out_all
-        z, zm = np.asarray(p["z"]), np.asarray(p["zm"])
-        data_vars = {
-            "I_dr": dv_tuple("I_dr", out["I_dr"]),
-            "I_df_d": dv_tuple("I_df_d", out["I_df_d"]),
-            "I_df_u": dv_tuple("I_df_u", out["I_df_u"]),
-            "F": dv_tuple("F", out["F"]),
-            "I_d": dv_tuple("I_d", out["I_dr"] + out["I_df_d"]),
-            "dwl": dv_tuple("dwl", np.asarray(p["dwl"])),
-            "lai": dv_tuple("lai", np.asarray(p["lai"])),
-            "dlai": dv_tuple("dlai", np.asarray(p["dlai"])),
-        }
-        for k, v in (self.absorption or {}).items():  # standard absorption calculations (layer in-out)
-            data_vars[k] = dv_tuple(k, v)
-        for name, arr in self.out_extra.items():  # the scheme's own absorption outputs
-            if name[:2] != "aI":
-                continue
-            if arr.shape[0] == z.size:
-                dims = ("z", "wl")
-            elif arr.shape[0] == zm.size:
-                dims = ("zm", "wl")
-            else:
-                raise ValueError("Scheme absorption output has too many or too few levels.")
-            try:
-                attrs = da_attrs(name[:-7])  # without the `_scheme` suffix
-            except KeyError:
-                raise Exception(f"Scheme absorbance variable {name[:-7]} not found in vmd.")
-            data_vars[name] = (dims, arr, attrs)
-        data_vars.update(psi=dv_tuple("psi", p["psi"]), sza=dv_tuple("sza", np.rad2deg(p["psi"])), G=dv_tuple("G", p["G"]),
-                         K_b=dv_tuple("K_b", p["K_b"]))
-        coords = {"z": dv_tuple("z", z), "wl": dv_tuple("wl", np.asarray(p["wl"])), "zm": dv_tuple("zm", zm),
-                  "wle": dv_tuple("wle", np.asarray(p["wle"]))}
-        attrs = {"info": info, "scheme_name": self.scheme["name"], "scheme_long_name": self.scheme["long_name"],
-                 "scheme_short_name": self.scheme["short_name"], "crt1d_version": __version__}
+        self._need_run("before creating the dataset")
+        p, out = self._p, self.out
+        values = {name: out[name] for name in _SOLUTION_VARS}
+        values["I_d"] = out["I_dr"] + out["I_df_d"]
+        values.update({name: np.asarray(p[name]) for name in ("dwl", "lai", "dlai")})
+        values.update(self.absorption or {})  # standard absorption calculations (layer in-out)
+        data_vars = {name: dv_tuple(name, v) for name, v in values.items()}
+        data_vars.update(self._scheme_absorption_vars(np.asarray(p["z"]).size))
+        scalars = {"psi": p["psi"], "sza": np.rad2deg(p["psi"]), "G": p["G"], "K_b": p["K_b"]}
+        data_vars.update({name: dv_tuple(name, v) for name, v in scalars.items()})
+        coords = {name: dv_tuple(name, np.asarray(p[name])) for name in ("z", "wl", "zm", "wle")}
+        attrs = {"info": info, "crt1d_version": __version__}
+        attrs.update({f"scheme_{k}": self.scheme[k] for k in ("name", "long_name", "short_name")})
         return Dataset(coords, data_vars, attrs)
 
     def to_xr(self, *, info=""):
