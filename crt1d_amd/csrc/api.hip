@@ -186,6 +186,35 @@ __global__ __launch_bounds__(MAXT) void k_absorb_bandsum(EpiArgs a, int b0, int 
   }
 }
 
+// The per-column tail of the band-sum kernels below: raw band sums A_g(k), D_g(k) (LDS) -> the level outputs, lanes over (level, group).
+// Streaming stores: the outputs are not read again by this kernel (1e5 x 38 x 100: 2.05 -> 1.91 ms).
+__device__ inline double column_kb(const EpiArgs& a, int c) {
+  const double psi = a.psi[c];
+  const int kind = a.g_kind[c];
+  const double G = (kind == CRT_G_TABLE) ? a.g_at_psi[c] : G_closed(kind, a.g_param ? a.g_param[c] : 0.0, cos(psi), sin(psi));
+  return G / cos(psi);
+}
+template <int NGT>
+__device__ inline void bandsum_finish(const EpiArgs& a, int c, const double* raw, const double* ends, const double* __restrict__ lai, double Kb, int l,
+                                      int nlanes) {
+  const int ng = a.ngroup, nl = a.nz - 1;
+  const long long ob = (long long)c * nl * ng;
+  for (int i = l; i < nl * ng; i += nlanes) {
+    const int k = i / ng, g = i - k * ng;
+    const double A = raw[(k * NGT + g) * 2], Dg = raw[(k * NGT + g) * 2 + 1];
+    const double fsl = exp(-Kb * ((lai[k] + lai[k + 1]) / 2));       // model.py:601-602
+    const double adr = (1 - exp(-Kb * (lai[k] - lai[k + 1]))) * Dg;  // :617-621
+    const double adf = A - adr;                                          // :628
+    __builtin_nontemporal_store(A, a.aI + ob + i);
+    __builtin_nontemporal_store(adf * fsl + adr, a.aI_sl + ob + i);      // :631-633
+    __builtin_nontemporal_store(adf * (1 - fsl), a.aI_sh + ob + i);
+  }
+  if (a.totals && l < 4 * ng) {  // incoming, reflected, transmitted, soil-reflected
+    const int g = l >> 2, q = l & 3;
+    a.totals[((long long)c * ng + g) * 4 + q] = ends[(q < 2 ? 2 * NGT : 0) + 2 * g + (q & 1)];
+  }
+}
+
 // k_absorb_bandsum_w: the same pass with ONE WAVE PER COLUMN (nb <= 512): lane l owns bands l, l + 64, ... (NBT of them), so
 // the cross-band reduction of a level costs one set of lane exchanges per COLUMN instead of one per wave of a multi-wave
 // workgroup -- the kernel above spends most of its instructions there (2 ngroup reductions x 18 VALU instructions x 5 waves per
@@ -193,7 +222,7 @@ __global__ __launch_bounds__(MAXT) void k_absorb_bandsum(EpiArgs a, int b0, int 
 // crt_internal.hpp: 5 instructions per value instead of 18).  No barriers, no cross-wave traffic: the waves of a workgroup are
 // independent columns.  The raw band sums A_g(k), D_g(k) go to LDS; at the end the lanes turn them into the level outputs
 // (level factors f_sl(k), 1 - e^{-K_b dlai_k} evaluated there, lanes over levels) and write them coalesced.
-template <int NBT, int CH, int NGT>
+template <int NBT, int CH, int NGT, bool PF = false>
 __global__ __launch_bounds__(256) void k_absorb_bandsum_w(EpiArgs a, int wpb, int per_wave) {
   extern __shared__ double lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -237,9 +266,9 @@ __global__ __launch_bounds__(256) void k_absorb_bandsum_w(EpiArgs a, int wpb, in
     wave_sum_store(v, dst, 2 * NGT, lane);
   };
   if (a.totals) end_terms(ends);  // ground: transmitted I_d[0], soil-reflected I_df_u[0]  (diagnostics.py:476-530)
-  for (int k0 = 0; k0 < nl; k0 += CH) {
+  // a chunk = CH levels: `fetch` issues its loads, `reduce` forms the level terms and the band sums
+  auto fetch = [&](int k0, double (&r1)[CH][NBT], double (&d1)[CH][NBT], double (&u1)[CH][NBT]) {
     const int nlev = min(CH, nl - k0);
-    double r1[CH][NBT], d1[CH][NBT], u1[CH][NBT];
 #pragma unroll
     for (int t = 0; t < CH; ++t)
       if (t < nlev) {
@@ -252,6 +281,9 @@ __global__ __launch_bounds__(256) void k_absorb_bandsum_w(EpiArgs a, int wpb, in
           u1[t][i] = __builtin_nontemporal_load(U + off);
         }
       }
+  };
+  auto reduce = [&](int k0, const double (&r1)[CH][NBT], const double (&d1)[CH][NBT], const double (&u1)[CH][NBT]) {
+    const int nlev = min(CH, nl - k0);
     double v[CH * NGT * 2];  // [t][g][A, D]
 #pragma unroll
     for (int t = 0; t < CH; ++t) {
@@ -274,28 +306,198 @@ __global__ __launch_bounds__(256) void k_absorb_bandsum_w(EpiArgs a, int wpb, in
       }
     }
     wave_sum_store(v, raw + (size_t)k0 * NGT * 2, nlev * NGT * 2, lane);
+  };
+  if constexpr (PF) {
+    // narrow spectra (one band per lane): a chunk is only CH rows of nb * 8 bytes per array, too little in flight to cover the
+    // HBM latency at the occupancy the registers allow -> the next chunk's loads are issued before this chunk is reduced
+    double rA[CH][NBT], dA[CH][NBT], uA[CH][NBT], rB[CH][NBT], dB[CH][NBT], uB[CH][NBT];
+    fetch(0, rA, dA, uA);
+    for (int k0 = 0; k0 < nl; k0 += 2 * CH) {
+      if (k0 + CH < nl) fetch(k0 + CH, rB, dB, uB);
+      reduce(k0, rA, dA, uA);
+      if (k0 + CH < nl) {
+        if (k0 + 2 * CH < nl) fetch(k0 + 2 * CH, rA, dA, uA);
+        reduce(k0 + CH, rB, dB, uB);
+      }
+    }
+  } else {
+    for (int k0 = 0; k0 < nl; k0 += CH) {
+      double r1[CH][NBT], d1[CH][NBT], u1[CH][NBT];
+      fetch(k0, r1, d1, u1);
+      reduce(k0, r1, d1, u1);
+    }
   }
   if (a.totals) end_terms(ends + 2 * NGT);  // canopy top: incoming I_d[top], reflected I_df_u[top]
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave: LDS operations complete in order; make the sums visible to all lanes
-  const double psi = a.psi[c];
-  const int kind = a.g_kind[c];
-  const double G = (kind == CRT_G_TABLE) ? a.g_at_psi[c] : G_closed(kind, a.g_param ? a.g_param[c] : 0.0, cos(psi), sin(psi));
-  const double Kb = G / cos(psi);
-  const double* __restrict__ lai = a.lai + (long long)c * nz;
-  const long long ob = (long long)c * nl * ng;
-  for (int i = lane; i < nl * ng; i += 64) {
-    const int k = i / ng, g = i - k * ng;
-    const double A = raw[(k * NGT + g) * 2], Dg = raw[(k * NGT + g) * 2 + 1];
-    const double fsl = exp(-Kb * ((lai[k] + lai[k + 1]) / 2));  // model.py:601-602
-    const double adr = (1 - exp(-Kb * (lai[k] - lai[k + 1]))) * Dg;  // :617-621
-    const double adf = A - adr;                                  // :628
-    a.aI[ob + i] = A;
-    a.aI_sl[ob + i] = adf * fsl + adr;                           // :631-633
-    a.aI_sh[ob + i] = adf * (1 - fsl);
+  bandsum_finish<NGT>(a, c, raw, ends, a.lai + (long long)c * nz, column_kb(a, c), lane, 64);
+}
+
+// k_absorb_bandsum_l: narrow spectra (32 < nb <= 48, even; nz <= 257): one wave per column, the lanes over LAYERS.
+//   * lanes over layers: in the kernel above a narrow spectrum leaves lanes idle and still pays the full cross-lane reduction per
+//     level.  Here a slab of LS + 1 = 17 consecutive rows of the three profiles is staged in LDS as the flat copy of its global run
+//     (16-byte loads into registers -- issued one slab ahead, in flight while the previous slab is reduced -- then 16-byte LDS
+//     writes) and lane (t = lane & 15, p = lane >> 4) sums layer k0 + t over the bands p, p + 4, ... serially; what is left of the
+//     reduction is the sum over the four p, four values per set of six lane swaps.
+//     Rows are nbp = nb or nb + 2 doubles apart in LDS, whichever is 2 (mod 4): the 16 layers of a read fall into 16 bank groups.
+//   * the head and the tail of a column have nothing in flight to hide behind, so they are kept short: everything the column needs
+//     (first slab, LAI levels, leaf optics, geometry) is requested in one go, the level factors (two exponentials per layer) are
+//     formed while the second slab is in flight, and the tail is LDS reads, three multiply-adds and streaming stores.
+//     Measured per column at 1e5 x 38 x 100 before that (wall_clock64 stamps): first slab after 7.7 us (three dependent round
+//     trips), 3.3 us per further slab, then 2.2 + 2.6 + 0.9 us (last reduction, tail arithmetic, store acknowledgement).
+//     (A persistent form -- waves walking columns w, w + G, ... with the next column's first slab prefetched -- was tried: the
+//     loop-carried state costs 316 registers, one wave per SIMD, 3.3 ms instead of 2.0; capped at 256 it spills, 2.3 ms.)
+template <int NGT>
+__global__ __launch_bounds__(64) void k_absorb_bandsum_l(EpiArgs a, int nbp) {
+  constexpr int LS = 16, NP = 4, NLD = 9;  // NLD 16-byte loads per lane cover 17 rows of <= 64 bands: 17 * 32 <= 9 * 64
+  constexpr int NLAI = 5;                  // LAI levels per lane: nz <= 64 * 4 + 1 (the launcher checks)
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int nz = a.nz, nb = a.nb, ng = a.ngroup, nl = nz - 1, nb2 = nb >> 1;
+  const int SS = (LS + 1) * nbp;          // one array's slab
+  double* slab = lds;                     // [3][LS + 1][nbp]
+  double* wts = slab + 3 * SS;            // [NGT + 1][nbp]: the groups' band weights, then 1 - (leaf_r + leaf_t) of the column
+  double* raw = wts + (NGT + 1) * nbp;    // [nl][NGT][2]: A_g(k), D_g(k)
+  double* ends = raw + 2 * NGT * nl;      // [2][NGT][2]
+  double* lai_s = ends + 4 * NGT;         // [nz]
+  double* lvl = lai_s + nz;               // [nl][2]: f_sl(k), 1 - e^{-K_b dlai_k}
+  // where this lane's i-th 16-byte piece of a slab goes in LDS (the same for every slab): piece lane + 64 i of the flat run
+  int dst[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = lane + 64 * i;
+    const int row = idx / nb2;
+    dst[i] = row * nbp + 2 * (idx - row * nb2);
   }
-  if (a.totals && lane < 4 * ng) {  // incoming, reflected, transmitted, soil-reflected
-    const int g = lane >> 2, q = lane & 3;
-    a.totals[((long long)c * ng + g) * 4 + q] = ends[(q < 2 ? 2 * NGT : 0) + 2 * g + (q & 1)];
+  const int t = lane & 15, p = lane >> 4;
+  const int slot = wave_sum4_slot(p);
+  const bool band_lane = lane < nb;
+  // registers of the slab in flight, and of the column it opens (only loaded with a column's first slab)
+  d2 sr[NLD], sd[NLD], su[NLD];
+  double c_lr = 0.0, c_lt = 0.0, c_lai[NLAI], c_psi = 0.0, c_gp = 0.0, c_ga = 0.0;
+  int c_kind = 0;
+  const int c = blockIdx.x;
+  auto fetch = [&](int k0) {
+    const long long cb2 = (long long)c * nz * nb2;
+    const d2* __restrict__ R2 = reinterpret_cast<const d2*>(a.I_dr) + cb2;
+    const d2* __restrict__ D2 = reinterpret_cast<const d2*>(a.I_df_d) + cb2;
+    const d2* __restrict__ U2 = reinterpret_cast<const d2*>(a.I_df_u) + cb2;
+    const int n2 = (min(LS, nl - k0) + 1) * nb2;
+    const unsigned base = (unsigned)k0 * (unsigned)nb2;  // nz * nb < 2^31 (checked by the launcher)
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (lane + 64 * i < n2) {
+        sr[i] = __builtin_nontemporal_load(R2 + base + lane + 64 * i);
+        sd[i] = __builtin_nontemporal_load(D2 + base + lane + 64 * i);
+        su[i] = __builtin_nontemporal_load(U2 + base + lane + 64 * i);
+      }
+    if (k0 == 0) {
+      const long long ib = (long long)c * a.col_stride + (band_lane ? lane : 0);
+      c_lr = a.leaf_r[ib];
+      c_lt = a.leaf_t[ib];
+#pragma unroll
+      for (int j = 0; j < NLAI; ++j) c_lai[j] = a.lai[(long long)c * nz + min(lane + 64 * j, nz - 1)];
+      c_psi = a.psi[c];
+      c_kind = a.g_kind[c];
+      c_gp = a.g_param ? a.g_param[c] : 0.0;
+      c_ga = a.g_at_psi ? a.g_at_psi[c] : 0.0;
+    }
+  };
+  auto end_terms = [&](int row, double* out) {  // sum_b w (I_dr + I_df_d), sum_b w I_df_u of slab row `row`
+    double v[2 * NGT];
+    const int o = row * nbp + (band_lane ? lane : 0);
+    const double rd = band_lane ? slab[o] + slab[SS + o] : 0.0, uu = band_lane ? slab[2 * SS + o] : 0.0;
+#pragma unroll
+    for (int g = 0; g < NGT; ++g) {
+      const double wg = wts[g * nbp + (band_lane ? lane : 0)];
+      v[2 * g] = wg * rd;
+      v[2 * g + 1] = wg * uu;
+    }
+    wave_sum_store(v, out, 2 * NGT, lane);
+  };
+  fetch(0);  // first: everything below queues up behind it
+  {  // band weights: all requested at once (a load inside `g < ng ? ... : 0` is waited for before the next one is issued)
+    double wv[NGT];
+#pragma unroll
+    for (int g = 0; g < NGT; ++g) wv[g] = a.band_w[(long long)min(g, ng - 1) * nb + (band_lane ? lane : 0)];
+    if (band_lane) {
+#pragma unroll
+      for (int g = 0; g < NGT; ++g) wts[g * nbp + lane] = g < ng ? wv[g] : 0.0;
+    }
+  }
+  for (int k0 = 0; k0 < nl; k0 += LS) {
+    const int nr = min(LS, nl - k0);
+    {  // the slab in flight -> LDS
+      const int n2 = (nr + 1) * nb2;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        if (lane + 64 * i < n2) {
+          *reinterpret_cast<d2*>(slab + dst[i]) = sr[i];
+          *reinterpret_cast<d2*>(slab + SS + dst[i]) = sd[i];
+          *reinterpret_cast<d2*>(slab + 2 * SS + dst[i]) = su[i];
+        }
+    }
+    if (k0 == 0) {  // ... and the column it opens
+      if (band_lane) wts[NGT * nbp + lane] = 1 - (c_lr + c_lt);  // :584
+#pragma unroll
+      for (int j = 0; j < NLAI; ++j)
+        if (lane + 64 * j < nz) lai_s[lane + 64 * j] = c_lai[j];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: LDS operations complete in order; the slab is visible to all lanes
+    if (k0 + LS < nl) fetch(k0 + LS);  // the next slab is in flight while this one is reduced
+    if (k0 == 0) {  // level factors of the column (model.py:601-602, 617-621), lanes over layers
+      const double G = (c_kind == CRT_G_TABLE) ? c_ga : G_closed(c_kind, c_gp, cos(c_psi), sin(c_psi));
+      const double Kb = G / cos(c_psi);
+      for (int k = lane; k < nl; k += 64) {
+        const double l0 = lai_s[k], l1 = lai_s[k + 1];
+        lvl[2 * k] = exp(-Kb * ((l0 + l1) / 2));
+        lvl[2 * k + 1] = 1 - exp(-Kb * (l0 - l1));
+      }
+      if (a.totals) end_terms(0, ends);  // ground: transmitted I_d[0], soil-reflected I_df_u[0]  (diagnostics.py:476-530)
+    }
+    double v[2 * NGT];
+#pragma unroll
+    for (int j = 0; j < 2 * NGT; ++j) v[j] = 0.0;
+    if (t < nr) {
+      const double* r0p = slab + t * nbp;
+      for (int b = p; b < nb; b += NP) {
+        const double r0 = r0p[b], r1 = r0p[nbp + b];
+        const double d0 = r0p[SS + b], d1 = r0p[SS + nbp + b];
+        const double u0 = r0p[2 * SS + b], u1 = r0p[2 * SS + nbp + b];
+        const double av = r1 - r0 + d1 - d0 + u0 - u1;  // :609
+        const double ar = wts[NGT * nbp + b] * r1;       // :617-621 without the level factor
+#pragma unroll
+        for (int g = 0; g < NGT; ++g) {
+          const double wg = wts[g * nbp + b];
+          v[2 * g] += wg * av;
+          v[2 * g + 1] += wg * ar;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < (2 * NGT + 3) / 4; ++j) {  // sum over the four p: afterwards DPP row p holds value 4 j + slot of its layer
+      const double z = swap_add16(swap_add32(v[4 * j], 4 * j + 1 < 2 * NGT ? v[4 * j + 1] : 0.0),
+                                  swap_add32(4 * j + 2 < 2 * NGT ? v[4 * j + 2] : 0.0, 4 * j + 3 < 2 * NGT ? v[4 * j + 3] : 0.0));
+      if (t < nr && 4 * j + slot < 2 * NGT) raw[(k0 + t) * NGT * 2 + 4 * j + slot] = z;
+    }
+    if (k0 + LS >= nl) {  // the column is complete
+      if (a.totals) end_terms(nr, ends + 2 * NGT);  // canopy top: incoming I_d[top], reflected I_df_u[top]
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const long long ob = (long long)c * nl * ng;
+      for (int i = lane; i < nl * ng; i += 64) {
+        const int k = i / ng, g = i - k * ng;
+        const double A = raw[(k * NGT + g) * 2], Dg = raw[(k * NGT + g) * 2 + 1];
+        const double fsl = lvl[2 * k];
+        const double adr = lvl[2 * k + 1] * Dg;  // :617-621
+        const double adf = A - adr;              // :628
+        __builtin_nontemporal_store(A, a.aI + ob + i);
+        __builtin_nontemporal_store(adf * fsl + adr, a.aI_sl + ob + i);  // :631-633
+        __builtin_nontemporal_store(adf * (1 - fsl), a.aI_sh + ob + i);
+      }
+      if (a.totals && lane < 4 * ng) {  // incoming, reflected, transmitted, soil-reflected
+        const int g = lane >> 2, q = lane & 3;
+        a.totals[((long long)c * ng + g) * 4 + q] = ends[(q < 2 ? 2 * NGT : 0) + 2 * g + (q & 1)];
+      }
+    }
   }
 }
 
@@ -387,26 +589,7 @@ __global__ __launch_bounds__(256) void k_absorb_bandsum_h(EpiArgs a, int wpb, in
   if (a.totals) end_terms(ends + 2 * NGT);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (!colok) return;
-  const double psi = a.psi[c];
-  const int kind = a.g_kind[c];
-  const double G = (kind == CRT_G_TABLE) ? a.g_at_psi[c] : G_closed(kind, a.g_param ? a.g_param[c] : 0.0, cos(psi), sin(psi));
-  const double Kb = G / cos(psi);
-  const double* __restrict__ lai = a.lai + (long long)c * nz;
-  const long long ob = (long long)c * nl * ng;
-  for (int i = l; i < nl * ng; i += 32) {
-    const int k = i / ng, g = i - k * ng;
-    const double A = raw[(k * NGT + g) * 2], Dg = raw[(k * NGT + g) * 2 + 1];
-    const double fsl = exp(-Kb * ((lai[k] + lai[k + 1]) / 2));       // model.py:601-602
-    const double adr = (1 - exp(-Kb * (lai[k] - lai[k + 1]))) * Dg;  // :617-621
-    const double adf = A - adr;                                      // :628
-    a.aI[ob + i] = A;
-    a.aI_sl[ob + i] = adf * fsl + adr;                               // :631-633
-    a.aI_sh[ob + i] = adf * (1 - fsl);
-  }
-  if (a.totals && l < 4 * ng) {
-    const int g = l >> 2, q = l & 3;
-    a.totals[((long long)c * ng + g) * 4 + q] = ends[(q < 2 ? 2 * NGT : 0) + 2 * g + (q & 1)];
-  }
+  bandsum_finish<NGT>(a, c, raw, ends, a.lai + (long long)c * nz, column_kb(a, c), l, 32);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -799,6 +982,23 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
   a.totals = totals;
   // measured (tools/epilogue_bench.py): nb = 20: 1.15 ms per wave-column vs 0.85 ms per half-wave-column; nb = 38: 1.11 vs 1.26 (the second band
   // slot of a half is nearly empty and doubles the per-band work) -> halves only up to 32 bands
+  const bool aligned16 = ((reinterpret_cast<uintptr_t>(I_dr) | reinterpret_cast<uintptr_t>(I_df_d) | reinterpret_cast<uintptr_t>(I_df_u)) & 15) == 0;
+  // measured (tools/bandsum_shapes.py, 9.1 GB of profiles): lanes over layers vs lanes over bands (one band per lane, next chunk prefetched):
+  //   1e5 x 34 x 100: 1.69 vs 1.83 ms;  1e5 x 38 x 100: 1.89 vs 2.09;  1e5 x 48 x 80: 1.85 vs 1.88;  1e5 x 64 x 60: 2.02 vs 1.66 -> up to 48 bands
+  if (a.nb > 32 && a.nb <= 48 && a.nb % 2 == 0 && aligned16 && a.nz <= 257 && (long long)a.nz * a.nb < (1ll << 31)) {  // lanes over layers
+    const int nl = a.nz - 1;
+    const int ngt = a.ngroup == 1 ? 1 : a.ngroup <= 3 ? 3 : 4;
+    const int nbp = (a.nb % 4 == 2) ? a.nb : a.nb + 2;
+    const size_t shl = (size_t)(3 * 17 * nbp + (ngt + 1) * nbp + 2 * ngt * nl + 4 * ngt + a.nz + 2 * nl) * sizeof(double);
+    if (shl <= 64 * 1024) {
+      hipStream_t sl = static_cast<hipStream_t>(stream);
+      const dim3 gl(a.ncol);
+      if (ngt == 1) hipLaunchKernelGGL((k_absorb_bandsum_l<1>), gl, dim3(64), shl, sl, a, nbp);
+      else if (ngt == 3) hipLaunchKernelGGL((k_absorb_bandsum_l<3>), gl, dim3(64), shl, sl, a, nbp);
+      else hipLaunchKernelGGL((k_absorb_bandsum_l<4>), gl, dim3(64), shl, sl, a, nbp);
+      return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+    }
+  }
   if (a.nb <= 32 && (long long)a.nz * a.nb < (1ll << 31)) {  // a column per half wave
     const int nl = a.nz - 1;
     const int ngt = a.ngroup == 1 ? 1 : a.ngroup <= 3 ? 3 : 4;
@@ -834,7 +1034,7 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
       auto launch = [&](auto ngt) {
         constexpr int NGT = decltype(ngt)::value;
         switch (nbt) {
-          case 1: hipLaunchKernelGGL((k_absorb_bandsum_w<1, 4, NGT>), grid, block, shw, sw, a, wpb, per_wave); break;
+          case 1: hipLaunchKernelGGL((k_absorb_bandsum_w<1, 4, NGT, true>), grid, block, shw, sw, a, wpb, per_wave); break;
           case 2: hipLaunchKernelGGL((k_absorb_bandsum_w<2, 4, NGT>), grid, block, shw, sw, a, wpb, per_wave); break;
           case 3: hipLaunchKernelGGL((k_absorb_bandsum_w<3, 4, NGT>), grid, block, shw, sw, a, wpb, per_wave); break;
           case 4: hipLaunchKernelGGL((k_absorb_bandsum_w<4, 2, NGT>), grid, block, shw, sw, a, wpb, per_wave); break;

@@ -111,10 +111,13 @@ def test_bonan_through_model_and_absorption(oracle):
     assert np.abs(y_sh - g["n79_9sky__aI_lsh"]).mean() < 1e-6
 
 
-@pytest.mark.parametrize("shape", [(37, 300, 60), (11, 38, 100), (9, 64, 33), (13, 20, 12), (5, 107, 61), (4, 512, 30), (3, 600, 20), (2, 1100, 9), (1, 36, 60)])
+@pytest.mark.parametrize("shape", [(37, 300, 60), (11, 38, 100), (9, 64, 33), (13, 20, 12), (5, 107, 61), (4, 512, 30), (3, 600, 20), (2, 1100, 9), (1, 36, 60),
+                                   (7, 34, 2), (5, 62, 18), (6, 40, 17), (3, 52, 130), (4, 37, 40), (3, 63, 35)])
 def test_epilogue_kernels_vs_oracle(oracle, shape):
-    """crt_hip_absorb_f64 / crt_hip_absorb_bandsum_f64 on every kernel path: a column per half wave (nb <= 64), per wave (nb <= 512),
-    multi-wave workgroups with band slices (beyond); even nb -> tiled flat walk of the seven per-band outputs, odd nb -> lane per band."""
+    """crt_hip_absorb_f64 / crt_hip_absorb_bandsum_f64 on every kernel path: a column per half wave (nb <= 32), a wave per column with the
+    lanes over layers (32 < nb <= 64, even; slabs of 16 layers: nz - 1 below, at and above multiples of 16), with the lanes over bands
+    (nb <= 512), multi-wave workgroups with band slices (beyond); even nb -> tiled flat walk of the seven per-band outputs, odd nb ->
+    lane per band."""
     import torch
 
     from crt1d_amd import batched, spectra, synth

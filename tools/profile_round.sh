@@ -39,6 +39,9 @@ CASES=(
 "zq_integrated|wfsq|$R/bench.py --scheme zq --variant integrated $B"
 "band_zq|wf|$R/bench.py --partition band --ncol 20000 --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline"
 "epilogue|wf|$R/tools/epilogue_bench.py 10000 300 60"
+"epilogue_nb38|wfsqi|$R/tools/epilogue_bench.py 100000 38 100"
+"zq_pa_nb38|wfsq|$R/bench.py --scheme zq_pa --nb 38 --nz 100 --ncol 100000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
+"zq_pa_nb107|wfsq|$R/bench.py --scheme zq_pa --nb 107 --ncol 30000 $B"
 )
 for entry in "${CASES[@]}"; do
   IFS='|' read -r name passes cmd <<< "$entry"
@@ -51,6 +54,9 @@ for entry in "${CASES[@]}"; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $d/pmc_FETCH_SIZE -- python3 $cmd > $d/pmc_FETCH_SIZE.log 2>&1 || echo "FETCH_SIZE pass failed for $name" | tee -a $OUT/progress.log
   if [[ "$passes" == *sq* ]]; then
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $d/pmc_SQ -- python3 $cmd > $d/pmc_SQ.log 2>&1 || echo "SQ pass failed for $name" | tee -a $OUT/progress.log
+  fi
+  if [[ "$passes" == *sqi* ]]; then  # instruction counts
+    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $d/pmc_SQI -- python3 $cmd > $d/pmc_SQI.log 2>&1 || echo "SQI pass failed for $name" | tee -a $OUT/progress.log
   fi
 done
 python3 $R/tools/summarize_profiles.py $OUT > $OUT/summary.json 2> $OUT/summary.err

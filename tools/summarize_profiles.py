@@ -81,6 +81,14 @@ def main(root):
                 wc = m.get("SQ_WAVE_CYCLES") or 1.0
                 sq[k] = {"means": m, "share_of_wave_cycles": {n: round(m[n] / wc, 3) for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS") if n in m}}
             e["sq"] = sq
+        f = find(os.path.join(d, "pmc_SQI"), "*counter_collection.csv")
+        if f:  # instruction counts per launch
+            acc = {}
+            for r in csv.DictReader(open(f)):
+                if any(s in r["Kernel_Name"] for s in SKIP):
+                    continue
+                acc.setdefault(short(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            e["sq_insts"] = {k: {n: sum(v) / len(v) for n, v in c.items()} for k, c in acc.items()}
         if dom and "bench" in e and isinstance(e["bench"], dict) and e["bench"].get("algorithmic_bytes_per_launch"):
             alg = e["bench"]["algorithmic_bytes_per_launch"]
             e["rocprof_avg_ms"] = ours[dom]["avg_us"] / 1e3
@@ -130,7 +138,7 @@ def shrink(root, dst):
             lines = [ln for ln in open(sj) if ln.startswith("{")]
             if lines:
                 open(os.path.join(out, "bench_line.json"), "w").write(lines[0])
-        for c in ("WRITE_SIZE", "FETCH_SIZE", "SQ"):
+        for c in ("WRITE_SIZE", "FETCH_SIZE", "SQ", "SQI"):
             f = find(os.path.join(src, "pmc_" + c), "*counter_collection.csv")
             if f:
                 rows = open(f).read().splitlines()
