@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) void k_absorb_bandsum_w(EpiArgs a, int wpb, in
     }
     wave_sum_store(v, dst, 2 * NGT, lane);
   };
+  const double Kb = column_kb(a, c);  // now, not in the tail: three dependent round trips with nothing else of the wave in flight there
   if (a.totals) end_terms(ends);  // ground: transmitted I_d[0], soil-reflected I_df_u[0]  (diagnostics.py:476-530)
   // a chunk = CH levels: `fetch` issues its loads, `reduce` forms the level terms and the band sums
   auto fetch = [&](int k0, double (&r1)[CH][NBT], double (&d1)[CH][NBT], double (&u1)[CH][NBT]) {
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void k_absorb_bandsum_w(EpiArgs a, int wpb, in
   }
   if (a.totals) end_terms(ends + 2 * NGT);  // canopy top: incoming I_d[top], reflected I_df_u[top]
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave: LDS operations complete in order; make the sums visible to all lanes
-  bandsum_finish<NGT>(a, c, raw, ends, a.lai + (long long)c * nz, column_kb(a, c), lane, 64);
+  bandsum_finish<NGT>(a, c, raw, ends, a.lai + (long long)c * nz, Kb, lane, 64);
 }
 
 // k_absorb_bandsum_l: narrow spectra (32 < nb <= 48, even; nz <= 257): one wave per column, the lanes over LAYERS.
