@@ -625,6 +625,10 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
   const int nb = a.nb, nz = a.nz, T = cfg.T;
   const int tid = threadIdx.x;
   const int c = blockIdx.x;
+  // the band's spectra are requested together with the column record (not after the barrier that publishes it): one round trip
+  // instead of two before the first level can be formed
+  BandIn bin = {};
+  if (tid < cfg.ncomp) bin = load_band<TIO>(a, c, tid < nb ? tid : 0, S::SOIL);
   {
     const double* src = a.ws + (long long)c * a.reclen;
     for (int i = tid; i < a.reclen; i += blockDim.x) lds[i] = src[i];
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
     const bool active = tid < nb;
     const int b = active ? tid : 0;
     S st;
-    st.init(rec, load_band<TIO>(a, c, b, S::SOIL), a);
+    st.init(rec, bin, a);
     int buf = 0;
     for (int j0 = 0; j0 < nz; j0 += T) {
       const int Tc = min(T, nz - j0);

@@ -719,8 +719,12 @@ __device__ __forceinline__ void tri_pipe_store(const SolveArgs& a, const PipeCfg
   }
 }
 
+// amdgpu_waves_per_eu(4): two 8-wave workgroups per CU need four waves per SIMD, i.e. <= 128 registers.  Left to itself the
+// register-staged M = 16 form (levels above ~80) takes 130 and only ONE workgroup stays resident: zq at 6000 x 300 x 100
+// 1.74 ms (0.73 of the peak) -> 1.55 ms (0.82) with the cap (12 bytes of scratch per lane).  profiles/r02/kernel_resources.txt lists
+// every kernel's registers / occupancy (hipcc -Rpass-analysis=kernel-resource-usage).
 template <class S, typename TIO, int M, int T, int MAXT, int RS>
-__global__ __launch_bounds__(MAXT) void k_tri_pipe(SolveArgs a, PipeCfg cfg) {
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4))) void k_tri_pipe(SolveArgs a, PipeCfg cfg) {
   static_assert(M % T == 0, "tile height must divide the checkpoint spacing");
   extern __shared__ double lds[];
   {
