@@ -417,7 +417,7 @@ __device__ __forceinline__ void tri_int_body(const SolveArgs& a, const IntArgs& 
 }
 
 template <class S, typename TIO, int M, int MAXT>
-__global__ __launch_bounds__(MAXT) void k_tri_int(SolveArgs a, IntArgs ia, int off_ck, int off_int) {
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(M <= 8 ? 5 : 3))) void k_tri_int(SolveArgs a, IntArgs ia, int off_ck, int off_int) {
   extern __shared__ double lds[];
   {
     const double* src = a.ws + (long long)blockIdx.x * a.reclen;
