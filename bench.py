@@ -190,17 +190,17 @@ def cpu_baseline(scheme, nb, nz, budget_s=15.0):
     return out
 
 
-def load_pmc_traffic(scheme, shape, f32=False, variant="profiles"):
-    """HBM bytes per launch of the solve kernel from the committed rocprofv3 --pmc summary (separate WRITE_SIZE / FETCH_SIZE passes
-    of this same command, profiles/pmc_traffic.json), if one exists for exactly this scheme / storage type / variant / launch shape."""
+def load_pmc_traffic(kernel, shape):
+    """HBM bytes per launch of the solve kernel from the committed rocprofv3 --pmc summaries (separate WRITE_SIZE / FETCH_SIZE passes of
+    a bench command with this launch shape, profiles/pmc_traffic.json), if one exists for exactly this kernel family (the name the
+    library reports up to its first blank: scheme and storage type included) and launch shape."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    want = scheme + ("_f32" if f32 else "") + ("_integrated" if variant == "integrated" else "")
+    fam = (kernel or "").split(" ")[0]
     try:
         with open(p) as f:
             d = json.load(f)
         for e in d.get("entries", []):
-            base = e["case"].split("_nb")[0].split("_nz")[0]
-            if base == want and e.get("shape") == list(shape):
+            if (e.get("kernel_reported_by_library") or "").split(" ")[0] == fam and e.get("shape") == list(shape):
                 return e.get("hbm_bytes_per_launch")
     except Exception:
         pass
@@ -607,7 +607,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": load_pmc_traffic(scheme, (ncol_kernel, nb_kernel, nz), f32, a.variant),
+            "traffic": load_pmc_traffic(kname, (ncol_kernel, nb_kernel, nz)),
             "algorithmic_bytes_per_launch": alg_bytes,
             "bytes_per_solve": bps,
             "launch_shape": [ncol_kernel, nb_kernel, nz],

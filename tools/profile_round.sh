@@ -38,6 +38,8 @@ CASES=(
 "n79_integrated|wfsq|$R/bench.py --scheme n79 --variant integrated $B"
 "zq_integrated|wfsq|$R/bench.py --scheme zq --variant integrated $B"
 "band_zq|wf|$R/bench.py --partition band --ncol 20000 --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline"
+"2s_125k|wf|$R/bench.py --scheme 2s --ncol 125000 --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-pcie"
+"band_cfg4|wf|$R/bench.py --partition band --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline"
 "epilogue|wf|$R/tools/epilogue_bench.py 10000 300 60"
 "epilogue_nb38|wfsqi|$R/tools/epilogue_bench.py 100000 38 100"
 "zq_pa_nb38|wfsq|$R/bench.py --scheme zq_pa --nb 38 --nz 100 --ncol 100000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
