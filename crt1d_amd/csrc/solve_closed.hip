@@ -810,6 +810,10 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
     // Longer tiles lose: T=11 at nb=128 leaves one workgroup per CU, 1.5 ms.
     size_t budget = target;
     if (S::HEAVY_INIT && 2 * plevel * 4 <= 40 * 1024) budget = 40 * 1024;
+    // f32 storage halves the stores but not the per-band set-up: for 2s three resident workgroups (tiles of 4 levels) cover it better than
+    // two with 8 (tools/ab_f32_T.py: 1e4 x 300 x 60 0.597 -> 0.510 ms, 6000 x 300 x 100 0.566 -> 0.494, 3334 x 300 x 60 0.235 -> 0.187;
+    // 4s indifferent, bl 2 % the other way: left at 8)
+    if (sizeof(TIO) == 4 && std::is_same<S, Sch2s>::value && 2 * plevel * 4 <= 40 * 1024) budget = 40 * 1024;
     // generic flush: whole lines whatever T is, so narrow spectra take short tiles and four or five workgroups per CU
     // (3e4 x 107 x 60, k_tile -> T=8 -> T=4: 2s 1.268 -> 1.285 -> 1.085 ms, bl 1.174 -> 1.136 -> 1.066, g77 2.174 -> 1.957 -> 1.861)
     if (!fused && pcomp <= 128 && budget > 32 * 1024) budget = 32 * 1024;
