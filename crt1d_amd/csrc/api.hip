@@ -745,13 +745,13 @@ __global__ __launch_bounds__(256) void k_absorb_tile(AbsArgs a, int T) {
         sl.x = dsl.x + adr.x;
         sl.y = dsl.y + adr.y;
         const long long o = o0 + i2;
-        reinterpret_cast<d2*>(a.o[0])[o] = av;
-        reinterpret_cast<d2*>(a.o[1])[o] = adf;
-        reinterpret_cast<d2*>(a.o[2])[o] = adr;
-        reinterpret_cast<d2*>(a.o[3])[o] = dsh;
-        reinterpret_cast<d2*>(a.o[4])[o] = sl;
-        reinterpret_cast<d2*>(a.o[5])[o] = dsl;
-        reinterpret_cast<d2*>(a.o[6])[o] = dsh;
+        __builtin_nontemporal_store(av, reinterpret_cast<d2*>(a.o[0]) + o);
+        __builtin_nontemporal_store(adf, reinterpret_cast<d2*>(a.o[1]) + o);
+        __builtin_nontemporal_store(adr, reinterpret_cast<d2*>(a.o[2]) + o);
+        __builtin_nontemporal_store(dsh, reinterpret_cast<d2*>(a.o[3]) + o);
+        __builtin_nontemporal_store(sl, reinterpret_cast<d2*>(a.o[4]) + o);
+        __builtin_nontemporal_store(dsl, reinterpret_cast<d2*>(a.o[5]) + o);
+        __builtin_nontemporal_store(dsh, reinterpret_cast<d2*>(a.o[6]) + o);
         p += dp;
         t += dt;
         if (p >= nb2) {

@@ -569,7 +569,7 @@ __global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {
 #pragma unroll
           for (int k = 0; k < S::NARR; ++k) v[k] = tv[(k * colrun + t * nb) / VW + f_p];
 #pragma unroll
-          for (int k = 0; k < S::NARR; ++k) reinterpret_cast<vt*>(a.o[k])[go] = v[k];
+          for (int k = 0; k < S::NARR; ++k) __builtin_nontemporal_store(v[k], reinterpret_cast<vt*>(a.o[k]) + go);
         }
       }
     } else {
@@ -698,10 +698,10 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
           vt v;
 #pragma unroll
           for (int w = 0; w < VW; ++w) v[w] = src[mis + VW * i + w];
-          gv[i] = v;
+          __builtin_nontemporal_store(v, gv + i);
         }
-        if (sid < mis) g[sid] = src[sid];
-        if (sid < tail) g[mis + nvec * VW + sid] = src[mis + nvec * VW + sid];
+        if (sid < mis) __builtin_nontemporal_store(src[sid], g + sid);
+        if (sid < tail) __builtin_nontemporal_store(src[mis + nvec * VW + sid], g + mis + nvec * VW + sid);
         // park the part-line [end, avail) in front of the other buffer's tile of this array
         const int npark = avail - end;
         if (sid < npark) tile[(buf ^ 1) * bufrun + k * colrun - npark + sid] = src[n + sid];
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
 #pragma unroll
         for (int k = 0; k < S::NARR; ++k) v[k] = tv[(k * colrun + t * nb) / VW + p];
 #pragma unroll
-        for (int k = 0; k < S::NARR; ++k) reinterpret_cast<vt*>(a.o[k])[go] = v[k];
+        for (int k = 0; k < S::NARR; ++k) __builtin_nontemporal_store(v[k], reinterpret_cast<vt*>(a.o[k]) + go);
         p += dp;
         t += dt;
         if (p >= nbv) {

@@ -68,7 +68,7 @@ __device__ inline void flush_array(const SolveArgs& a, const double* rec, const 
     vt v;
     v.x = (TIO)elem(mis + 2 * i);
     v.y = (TIO)elem(mis + 2 * i + 1);
-    g2[i] = v;
+    g2[i] = v;  // (plain stores: the runs of this flush begin and end inside 128-B lines, which L2 has to merge)
   }
   if (tid == 0) {
     if (mis) g[0] = (TIO)elem(0);
@@ -93,6 +93,20 @@ __device__ inline void flush_arrays(const SolveArgs& a, const double* rec, const
 // them: (level, band) advance incrementally, the staged values are read once (the compiler merges the LDS reads of the value<>()
 // expressions), and every array gets its 16-byte store.  Same expressions as flush_array -> same bits.
 // CLS = 0: arrays with nz rows, CLS = 1: arrays with nz - 1 rows (n79's per-leaf-area absorption).
+// A pair of bands of one output row.  Arrays with nz rows per column: a column is 8 nz nb bytes and a tile of T rows a whole number of
+// 128-B lines at the band counts of the fused flush that matter (300 bands: 75 lines per 4 rows) -> streaming stores, nothing is read
+// back (2s 0.92 -> 0.85 ms, zq 1.57 -> 1.50 at 1e4 x 300 x 60).  Arrays with nz - 1 rows (n79's absorbed fluxes) start every column
+// and end every tile inside a line: those part-lines are left to L2 to merge (plain stores; streaming them cost n79 3 %).
+// The choice is per SCHEME (all arrays of zq have nz rows; n79 keeps plain stores for all six: choosing per array inside the unrolled
+// loop over the arrays cost zq 7 %).
+template <class S, typename TIO>
+__device__ __forceinline__ void store_rows(TIO __attribute__((ext_vector_type(2))) * p, TIO __attribute__((ext_vector_type(2))) v) {
+  if constexpr (S::out_rows(S::NOUT - 1, 8) == 8)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+
 template <class S, typename TIO, int CLS, int ARR, class F>
 __device__ __forceinline__ void for_class(int nz, F&& f) {
   if constexpr (ARR < S::NOUT) {
@@ -128,7 +142,7 @@ __device__ inline void flush_flat_class(const SolveArgs& a, const double* rec, c
       vt v;
       v.x = (TIO)S::template value<ARRI>(rec, nz, j0 + t, bcx, invmu, tile, tstride, e);
       v.y = (TIO)S::template value<ARRI>(rec, nz, j0 + t2, bcy, invmu, tile, tstride, e + 1);
-      *reinterpret_cast<vt*>(outp<TIO>(a.o[ARRI]) + g0 + e) = v;
+      *reinterpret_cast<vt*>(outp<TIO>(a.o[ARRI]) + g0 + e) = v;  // plain: part-lines at both ends of the run (streaming stores: n79 at 107 bands 1.59 -> 1.76 ms)
     });
     e += step;
     b += db;
@@ -202,7 +216,7 @@ __device__ inline void flush_fused(const SolveArgs& a, const double* rec, const 
         vt v;
         v.x = (TIO)o[k].x;
         v.y = (TIO)o[k].y;
-        reinterpret_cast<vt*>(a.o[k])[((long long)c * rows + j) * nb2 + fm.p] = v;
+        store_rows<S, TIO>(reinterpret_cast<vt*>(a.o[k]) + ((long long)c * rows + j) * nb2 + fm.p, v);
       }
     }
   }
@@ -624,7 +638,7 @@ __device__ __forceinline__ void tri_pipe_store_rs(const SolveArgs& a, const Pipe
               w.y = (TIO)o[r].y;
               // wave-uniform column base (scalar registers) + one 32-bit lane offset shared by all arrays
               vt* colbase = reinterpret_cast<vt*>(a.o[r]) + (long long)c * rows * nb2;
-              colbase[(unsigned)(j * nb2 + pp[it])] = w;
+              store_rows<S, TIO>(colbase + (unsigned)(j * nb2 + pp[it]), w);
             }
           }
         }
@@ -703,7 +717,7 @@ __device__ __forceinline__ void tri_pipe_store(const SolveArgs& a, const PipeCfg
               v.x = (TIO)o[r].x;
               v.y = (TIO)o[r].y;
               vt* colbase = reinterpret_cast<vt*>(a.o[r]) + (long long)c * rows * nb2;
-              colbase[(unsigned)(j * nb2 + p)] = v;
+              store_rows<S, TIO>(colbase + (unsigned)(j * nb2 + p), v);
             }
           }
         }

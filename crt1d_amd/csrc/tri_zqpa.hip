@@ -46,10 +46,10 @@ __global__ __launch_bounds__(256) void k_zqpa_interp(InterpArgs a) {
     const double up = ua + (ub - ua) * w;  // :361
     const double idr = ldio<TIO>(a.I_dr0, (long long)c * a.col_stride + b) * ekl[j];  // :354-355
     const long long o = (long long)c * nz * nb + i;
-    outp<TIO>(a.o[0])[o] = (TIO)idr;
-    outp<TIO>(a.o[1])[o] = (TIO)dn;
-    outp<TIO>(a.o[2])[o] = (TIO)up;
-    outp<TIO>(a.o[3])[o] = (TIO)(idr * invmu + 2 * up + 2 * dn);  // :412
+    __builtin_nontemporal_store((TIO)idr, outp<TIO>(a.o[0]) + o);
+    __builtin_nontemporal_store((TIO)dn, outp<TIO>(a.o[1]) + o);
+    __builtin_nontemporal_store((TIO)up, outp<TIO>(a.o[2]) + o);
+    __builtin_nontemporal_store((TIO)(idr * invmu + 2 * up + 2 * dn), outp<TIO>(a.o[3]) + o);  // :412
   }
 }
 
@@ -122,10 +122,10 @@ __device__ __forceinline__ void zqpa_pipe_store(const SolveArgs& a, const PipeCf
           const d2 dn = da + (db - da) * w;  // :360
           const d2 up = ua + (ub - ua) * w;  // :361
           const d2 idr = bandc2[p] * ekl[j];  // :354-355
-          o0[idx] = cvt(idr);
-          o1[idx] = cvt(dn);
-          o2[idx] = cvt(up);
-          o3[idx] = cvt(idr * invmu + 2 * up + 2 * dn);  // :412
+          __builtin_nontemporal_store(cvt(idr), o0 + idx);
+          __builtin_nontemporal_store(cvt(dn), o1 + idx);
+          __builtin_nontemporal_store(cvt(up), o2 + idx);
+          __builtin_nontemporal_store(cvt(idr * invmu + 2 * up + 2 * dn), o3 + idx);  // :412
           p += dp;
           t += dt;
           if (p >= nb2) {
