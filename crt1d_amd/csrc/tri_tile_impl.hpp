@@ -117,8 +117,9 @@ __device__ __forceinline__ void for_class(int nz, F&& f) {
 
 template <class S, typename TIO, int CLS>
 __device__ inline void flush_flat_class(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride,
-                                        int c, int j0, int T, double invmu, int tid, int nthr) {
+                                        int c, int j0, int T, double invmu, int tid, int nthr, bool stream) {
   typedef TIO vt __attribute__((ext_vector_type(2)));
+  constexpr int LINE = 128 / (int)sizeof(TIO);
   const int nb = a.nb, nz = a.nz, rows = nz - CLS;
   const int nr = min(j0 + T, rows) - j0;
   if (nr <= 0) return;
@@ -137,12 +138,21 @@ __device__ inline void flush_flat_class(const SolveArgs& a, const double* rec, c
     const bool wrap = b + 1 >= nb;
     const int t2 = wrap ? t + 1 : t, b2 = wrap ? 0 : b + 1;
     const double bcx = bandc[b], bcy = bandc[b2];
+    // the 128-B line this pair lies in is written completely by this run?  (array bases are line-aligned when `stream` is set.)
+    // Whole lines are streamed; the part-lines at the two ends of the run wait in L2 for their other half (plain stores --
+    // streaming those too: n79 at 107 bands 1.59 -> 1.76 ms)
+    const long long l0 = (g0 + e) & ~(long long)(LINE - 1);
+    const bool whole = stream && l0 >= g0 && l0 + LINE <= g0 + n;
     for_class<S, TIO, CLS, 0>(nz, [&](auto arr) {
       constexpr int ARRI = decltype(arr)::value;
       vt v;
       v.x = (TIO)S::template value<ARRI>(rec, nz, j0 + t, bcx, invmu, tile, tstride, e);
       v.y = (TIO)S::template value<ARRI>(rec, nz, j0 + t2, bcy, invmu, tile, tstride, e + 1);
-      *reinterpret_cast<vt*>(outp<TIO>(a.o[ARRI]) + g0 + e) = v;  // plain: part-lines at both ends of the run (streaming stores: n79 at 107 bands 1.59 -> 1.76 ms)
+      vt* dst = reinterpret_cast<vt*>(outp<TIO>(a.o[ARRI]) + g0 + e);
+      if (whole)
+        __builtin_nontemporal_store(v, dst);
+      else
+        *dst = v;
     });
     e += step;
     b += db;
@@ -170,17 +180,20 @@ __device__ inline void flush_flat_class(const SolveArgs& a, const double* rec, c
 
 template <class S, typename TIO>
 __device__ inline void flush_flat(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride, int c,
-                                  int j0, int T, double invmu, int tid, int nthr) {
-  flush_flat_class<S, TIO, 0>(a, rec, bandc, tile, tstride, c, j0, T, invmu, tid, nthr);
-  if constexpr (S::out_rows(S::NOUT - 1, 8) != 8) flush_flat_class<S, TIO, 1>(a, rec, bandc, tile, tstride, c, j0, T, invmu, tid, nthr);
+                                  int j0, int T, double invmu, int tid, int nthr, bool stream) {
+  flush_flat_class<S, TIO, 0>(a, rec, bandc, tile, tstride, c, j0, T, invmu, tid, nthr, stream);
+  if constexpr (S::out_rows(S::NOUT - 1, 8) != 8) flush_flat_class<S, TIO, 1>(a, rec, bandc, tile, tstride, c, j0, T, invmu, tid, nthr, stream);
 }
 
 // host side: may the flat fused flush be used?  Every output array must start on a pair boundary (2 * sizeof(TIO)).
 template <class S, typename TIO>
-inline bool flat_flush_ok(const SolveArgs& a) {
-  for (int i = 0; i < S::NOUT; ++i)
-    if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) return false;
-  return true;
+inline int flat_flush_ok(const SolveArgs& a) {  // 0: no; 1: yes; 2: yes, and every array starts on a 128-B line (whole lines of a run are streamed)
+  int mode = 2;
+  for (int i = 0; i < S::NOUT; ++i) {
+    if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) return 0;
+    if (reinterpret_cast<uintptr_t>(a.o[i]) & 127) mode = 1;
+  }
+  return mode;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -302,7 +315,7 @@ __device__ __forceinline__ void tri_tile_body(const SolveArgs& a, const TriCfg& 
           if constexpr (FUSED)
             flush_fused<S, TIO, T>(a, rec, bandc, tile, c, k, fm, invmu);
           else if (cfg.flat)
-            flush_flat<S, TIO>(a, rec, bandc, tile, tstride, c, k, T, invmu, tid, nthr);
+            flush_flat<S, TIO>(a, rec, bandc, tile, tstride, c, k, T, invmu, tid, nthr, cfg.flat == 2);
           else
             flush_arrays<S, TIO, 0>(a, rec, bandc, tile, tstride, c, k, T, invmu, inv_nb, tid, nthr);
           lds_barrier();
@@ -341,7 +354,7 @@ int launch_mt(const SolveArgs& a, hipStream_t s, int nthr) {
   cfg.off_bc = (a.reclen + 1) & ~1;
   cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
   cfg.off_tile = cfg.off_ck + 2 * cfg.nck * nthr;
-  cfg.flat = !FUSED && a.tune[13] != 1 && flat_flush_ok<S, TIO>(a);
+  cfg.flat = (!FUSED && a.tune[13] != 1) ? flat_flush_ok<S, TIO>(a) : 0;
   const size_t sh = ((size_t)cfg.off_tile + (size_t)S::NST * T * a.nb) * sizeof(double);
   if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
   const void* fn = nthr <= 256 ? (const void*)k_tri_tile<S, TIO, M, T, 256, FUSED> : nthr <= 512 ? (const void*)k_tri_tile<S, TIO, M, T, 512, FUSED>
@@ -669,7 +682,7 @@ __device__ __forceinline__ void tri_pipe_store_generic(const SolveArgs& a, const
       if (k > kend) continue;
       lds_barrier();  // tile `buf` is complete
       if (cfg.flat)
-        flush_flat<S, TIO>(a, rec, bandc, tile + buf * bstride, tstride, c, k, min(T, kend - k + 1), invmu, sid, nst);
+        flush_flat<S, TIO>(a, rec, bandc, tile + buf * bstride, tstride, c, k, min(T, kend - k + 1), invmu, sid, nst, cfg.flat == 2);
       else
         flush_arrays<S, TIO, 0>(a, rec, bandc, tile + buf * bstride, tstride, c, k, min(T, kend - k + 1), invmu, inv_nb, sid, nst);
       buf ^= 1;
@@ -780,7 +793,7 @@ int launch_pipe_generic(const SolveArgs& a, hipStream_t s, int nstore_waves) {
   cfg.off_bc = (a.reclen + 1) & ~1;
   cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
   cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
-  cfg.flat = a.tune[13] != 1 && flat_flush_ok<S, TIO>(a);
+  cfg.flat = a.tune[13] != 1 ? flat_flush_ok<S, TIO>(a) : 0;
   const size_t sh = ((size_t)cfg.off_tile + (size_t)2 * S::NST * T * a.nb) * sizeof(double);
   if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
   auto kern = k_tri_pipe<S, TIO, M, T, 512, -1>;
