@@ -220,12 +220,12 @@ int crt_hip_buffer_alloc_set(int32_t n, const size_t* bytes, void** ptrs) {
       classified += k;
       most = std::max(most, k);
     }
-    // the classes other than the largest one can supply 40 % of the selection (ambiguous chunks count for nothing)
-    return classified - most >= (need * 2 + 4) / 5;
+    // the classes other than the largest one can supply half of the selection (ambiguous chunks count for nothing)
+    return classified - most >= (need + 1) / 2;
   };
   // Gathering: first `need` chunks, whatever they are.  If they cannot be balanced (a process often starts inside a run of
   // 10-35 GB of one class), keep allocating and classifying chunks -- holding everything, so that the driver has to move on to
-  // other memory -- until the other classes can supply 40 % of the request or the exploration budget (memory held at one time)
+  // other memory -- until the other classes can supply half of the request or the exploration budget (memory held at one time)
   // is spent; ~1.7 ms per chunk (create + map + probe), i.e. ~0.15 s for 40 GB.  (Large unmapped "spacer" allocations do not
   // move the driver's cursor for 512 MB requests -- they are served from other free blocks -- and cost 0.3 s each: tried, dropped.)
   // Surplus chunks are released before returning, rarest classes kept.
