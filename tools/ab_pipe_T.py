@@ -7,7 +7,8 @@ for scheme in ("4s", "2s", "bl"):
     cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
     plan = batched.Plan(scheme, cols, bands)
     plan(); torch.cuda.synchronize()
-    variants = {"default": {}, "T=2 s3": {4: 2, 3: 3}, "T=2 s2": {4: 2, 3: 2}, "T=3 s3": {4: 3, 3: 3}, "T=4 s4": {4: 4, 3: 4}, "T=6 s3": {4: 6, 3: 3}}
+    variants = {"default": {}, "T=2 s3": {4: 2, 3: 3}, "T=2 s2": {4: 2, 3: 2}, "T=4 s2": {4: 4, 3: 2}, "T=4 s4": {4: 4, 3: 4}, "T=4 s5": {4: 4, 3: 5}, "T=6 s3": {4: 6, 3: 3},
+                "k_tile T=4": {2: 4}, "k_tile T=8": {2: 4, 1: 8}}
     res = {k: [] for k in variants}; names = {}
     st = torch.cuda.current_stream()
     for rnd in range(5):
