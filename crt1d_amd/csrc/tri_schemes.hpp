@@ -8,6 +8,23 @@ namespace {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+// the five spectra of one (column, band); the pipeline kernels request them together with the column record, before the barrier
+// that publishes the record (one round trip instead of two ahead of the forward sweep)
+struct TriBand {
+  double I_dr0, I_df0, leaf_r, leaf_t, soil_r;
+};
+template <typename TIO>
+__device__ inline TriBand load_tri_band(const SolveArgs& a, int c, int b) {
+  const long long i = (long long)c * a.col_stride + b;
+  TriBand in;
+  in.I_dr0 = ldio<TIO>(a.I_dr0, i);
+  in.I_df0 = ldio<TIO>(a.I_df0, i);
+  in.leaf_r = ldio<TIO>(a.leaf_r, i);
+  in.leaf_t = ldio<TIO>(a.leaf_t, i);
+  in.soil_r = ldio<TIO>(a.soil_r, i);
+  return in;
+}
+
 // ------------------------------------------------------------------------------------------
 // n79 (crt1d/solvers/_solve_n79.py:70-155).  Even row k <-> upward flux at level k, k = 0 .. nz-1.
 struct TriN79 {
@@ -23,12 +40,14 @@ struct TriN79 {
 
   template <typename TIO>
   __device__ inline void init(const double* rec, const SolveArgs& a, int c, int b) {
-    const long long i = (long long)c * a.col_stride + b;
-    swb = ldio<TIO>(a.I_dr0, i);
-    swd = ldio<TIO>(a.I_df0, i);
-    rho = ldio<TIO>(a.leaf_r, i);
-    tau = ldio<TIO>(a.leaf_t, i);
-    alb = ldio<TIO>(a.soil_r, i);
+    init_band(rec, a, load_tri_band<TIO>(a, c, b));
+  }
+  __device__ inline void init_band(const double* rec, const SolveArgs&, const TriBand& in) {
+    swb = in.I_dr0;
+    swd = in.I_df0;
+    rho = in.leaf_r;
+    tau = in.leaf_t;
+    alb = in.soil_r;
     oma = 1 - (rho + tau);  // :56,145
     irho = fast_rcp(rho);
     invmu = rec[S_INVMU];
@@ -133,7 +152,10 @@ struct TriN79U : TriN79 {
   double refld, k_dn, k_src, itrand, omt_oma;  // back
   template <typename TIO>
   __device__ inline void init(const double* rec, const SolveArgs& a, int c, int b) {
-    TriN79::init<TIO>(rec, a, c, b);
+    init_band(rec, a, load_tri_band<TIO>(a, c, b));
+  }
+  __device__ inline void init_band(const double* rec, const SolveArgs& a, const TriBand& in) {
+    TriN79::init_band(rec, a, in);
     const int nz = a.nz;
     layer(rec, nz, 1, r, s);
     rr = r * r;
@@ -195,11 +217,13 @@ struct TriZq {
 
   template <typename TIO>
   __device__ inline void init(const double* rec, const SolveArgs& a, int c, int b) {
-    const long long i = (long long)c * a.col_stride + b;
-    I_dr0 = ldio<TIO>(a.I_dr0, i);
-    I_df0 = ldio<TIO>(a.I_df0, i);
-    const double bL = ldio<TIO>(a.leaf_r, i), tL = ldio<TIO>(a.leaf_t, i);
-    rho = ldio<TIO>(a.soil_r, i);
+    init_band(rec, a, load_tri_band<TIO>(a, c, b));
+  }
+  __device__ inline void init_band(const double* rec, const SolveArgs&, const TriBand& in) {
+    I_dr0 = in.I_dr0;
+    I_df0 = in.I_df0;
+    const double bL = in.leaf_r, tL = in.leaf_t;
+    rho = in.soil_r;
     const double mu = rec[S_MU], t = rec[S_TAUI], t_psi = rec[S_TPSI];
     invmu = rec[S_INVMU];
     const double aL = 1 - (bL + tL);                                             // :87

@@ -524,7 +524,7 @@ struct PipeCfg {
 };
 
 template <class S, typename TIO, int M, int T, int RS, int NSTG = S::NST>
-__device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
+__device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeCfg& cfg, double* lds, const TriBand* band = nullptr) {
   const int nb = a.nb, nz = a.nz;
   const int tid = threadIdx.x, nthr = cfg.ncomp;
   const int c = blockIdx.x;
@@ -536,7 +536,10 @@ __device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeC
   const bool active = tid < nb;
   const int b = active ? tid : 0;
   S st;
-  st.template init<TIO>(rec, a, c, b);
+  if (band)  // requested by the kernel together with the record (zq_pa)
+    st.init_band(rec, a, *band);
+  else
+    st.template init<TIO>(rec, a, c, b);
   if (active) bandc[b] = st.band_const();
   const int K = S::rows(nz);
   double e, f;

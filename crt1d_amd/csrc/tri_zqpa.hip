@@ -266,6 +266,8 @@ __device__ __forceinline__ void zqpa_pipe_store_flat(const SolveArgs& a, const P
 template <typename TIO, int M, int T, int MAXT, bool FLAT>
 __global__ __launch_bounds__(MAXT) void k_zqpa_pipe(SolveArgs a, PipeCfg cfg) {
   extern __shared__ double lds[];
+  TriBand band = {};  // requested together with the record (see TriBand): 104 registers leave room for it here, not in k_tri_pipe (126)
+  if ((int)threadIdx.x < cfg.ncomp) band = load_tri_band<TIO>(a, blockIdx.x, (int)threadIdx.x < a.nb ? threadIdx.x : 0);
   {
     const double* src = a.ws + (long long)blockIdx.x * a.reclen;
     for (int i = threadIdx.x; i < a.reclen; i += blockDim.x) lds[i] = src[i];
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(MAXT) void k_zqpa_pipe(SolveArgs a, PipeCfg cfg) {
       zqpa_pipe_store<TIO, M, T>(a, cfg, lds);
     return;
   }
-  tri_pipe_compute<TriZqPa, TIO, M, T, 0, 2>(a, cfg, lds);
+  tri_pipe_compute<TriZqPa, TIO, M, T, 0, 2>(a, cfg, lds, &band);
 }
 
 // returns CRT_ERR_UNSUPPORTED when the shape does not fit (caller falls back to the two-kernel path)
