@@ -543,13 +543,11 @@ __device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeC
   if (active) bandc[b] = st.band_const();
   const int K = S::rows(nz);
   double e, f;
-  st.first(rec, nz, e, f);
-  ck[0] = e;
-  ck[nthr] = f;
+  st.first(rec, nz, e, f);  // (not kept: segment 0 starts from first() again -- one checkpoint pair per lane less, 5 KB at 300 bands)
   for (int k = 0; k + 1 < K; ++k) {
     st.advance(k, rec, nz, e, f);
     if ((k + 1) % M == 0) {
-      const int sidx = (k + 1) / M;
+      const int sidx = (k + 1) / M - 1;  // checkpoint of segment sidx + 1
       ck[(2 * sidx) * nthr] = e;
       ck[(2 * sidx + 1) * nthr] = f;
     }
@@ -559,8 +557,12 @@ __device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeC
     const int k0 = seg * M;
     const int kend = min(k0 + M - 1, K - 1);
     double be[M], bf[M];
-    be[0] = ck[(2 * seg) * nthr];
-    bf[0] = ck[(2 * seg + 1) * nthr];
+    if (seg == 0) {
+      st.first(rec, nz, be[0], bf[0]);
+    } else {
+      be[0] = ck[(2 * (seg - 1)) * nthr];
+      bf[0] = ck[(2 * (seg - 1) + 1) * nthr];
+    }
 #pragma unroll
     for (int i = 1; i < M; ++i) {
       be[i] = be[i - 1];
@@ -792,7 +794,7 @@ int launch_pipe_generic(const SolveArgs& a, hipStream_t s, int nstore_waves) {
   const int K = S::rows(a.nz);
   PipeCfg cfg{};
   cfg.ncomp = ncomp;
-  cfg.nck = (K - 1) / M + 1;
+  cfg.nck = (K - 1) / M;  // checkpoints kept: segments 1 .. (K - 1) / M (segment 0 restarts from first())
   cfg.off_bc = (a.reclen + 1) & ~1;
   cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
   cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
@@ -818,7 +820,7 @@ int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves, bool reg
   const int K = S::rows(a.nz);
   PipeCfg cfg{};
   cfg.ncomp = ncomp;
-  cfg.nck = (K - 1) / M + 1;
+  cfg.nck = (K - 1) / M;  // checkpoints kept: segments 1 .. (K - 1) / M (segment 0 restarts from first())
   cfg.off_bc = (a.reclen + 1) & ~1;
   cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
   cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
