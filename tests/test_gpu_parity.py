@@ -59,7 +59,9 @@ def test_hip_vs_oracle_synthetic(torch_cuda, oracle, scheme, shape, uniform):
     # 2s: every h_i/sigma term (_solve_2s.py:101-125) is a removable singularity at
     # sigma = (mu_bar K)^2 + c^2 - b^2 -> 0; two fp64 evaluations with different operation order differ by
     # ~eps/|sigma| there (|sigma| down to ~3e-6 on this generator -> ~5e-11).  Same holds for the reference.
-    tol = 1e-9 if scheme == "2s" else 1e-11
+    # bf: (e^{-K_b L} - e^{-k_d L}) / (k_d - K_b) (B&F eq. 8, _solve_bf.py:95) is a removable singularity of the same kind at k_d = K_b:
+    # up to 3e-10 over random columns (tools/fuzz_parity.py), 1e-11 on this test's seeds
+    tol = 1e-9 if scheme in ("2s", "bf") else 1e-11
     for k, v in got.items():
         assert np.all(np.isfinite(v)), k
         # n79 aI_ls*: (1 - tau_d(dlai)) / dlai with dlai down to ~1e-3 (nz = 60) ... ~3e-4 (nz = 100) on the ragged profiles turns
