@@ -599,6 +599,26 @@ def main():
         fill_gbs = 8 * n / t_fill / 1e9
         copy_gbs = 2 * 8 * n / t_copy / 1e9
         del buf, src
+        # the flush of the solve kernel alone (streaming stores, all arrays in step) on the plan's OWN output arrays: the store rate this
+        # placement allows.  fp64 profile outputs only; the arrays are overwritten, so the plan is run once more afterwards.
+        store_set_gbs = None
+        outs = getattr(main_plan, "out", None)
+        if a.variant == "profiles" and not f32 and isinstance(outs, dict):
+            full = [v for v in outs.values() if v.dtype == torch.float64 and tuple(v.shape) == (ncol_kernel, nz, nb_kernel)]
+            if full and (nz * nb_kernel) % 2 == 0:
+                import ctypes
+
+                ptrs = (ctypes.c_void_p * len(full))(*[v.data_ptr() for v in full])
+                import math
+
+                t_run = 16 // math.gcd(nb_kernel, 16)  # levels per run: the shortest whole number of 128-B lines, at least 4 levels
+                while t_run < 4:
+                    t_run *= 2
+                run = t_run * nb_kernel
+                t_set = timed(lambda: lib.crt_hip_probe_store_set_f64(ptrs, len(full), ncol_kernel, nz * nb_kernel, run, 0.5, stream.cuda_stream))
+                store_set_gbs = 8 * len(full) * ncol_kernel * nz * nb_kernel / t_set / 1e9
+                main_plan()
+                torch.cuda.synchronize(dev)
         roof = {
             "bound": "hbm",
             "kernel": kname,
@@ -617,9 +637,11 @@ def main():
             "kernel_ms_max": kt[-1],
             "kernel_ms_avg_torch_empty_outputs": k_ms_plain,
             "k0_ms": k0_ms,
-            "measured_fill_GBs": fill_gbs,
+            "measured_fill_GBs": fill_gbs,  # linear fill of one 4 GiB buffer (one memory class at a time): a yardstick, not the ceiling
             "measured_copy_GBs": copy_gbs,
+            "measured_store_set_GBs": store_set_gbs,  # the kernel's own flush pattern on the kernel's own output arrays
             "frac_of_measured_fill": achieved / fill_gbs,
+            "frac_of_measured_store_set": (achieved / store_set_gbs) if store_set_gbs else None,
         }
 
     # ---- PCIe-inclusive step (N = 1, column partition): H2D of the per-band inputs + K0 + solve + D2H of every profile ----

@@ -107,6 +107,7 @@ EXPORTS = [
     "crt_hip_last_kernel",
     "crt_hip_probe_fill_f64",
     "crt_hip_probe_copy_f64",
+    "crt_hip_probe_store_set_f64",
 ]
 
 _lib = None
@@ -195,6 +196,8 @@ def load():
     lib.crt_hip_probe_fill_f64.argtypes = [_vp, ctypes.c_size_t, ctypes.c_double, _vp]
     lib.crt_hip_probe_copy_f64.restype = ctypes.c_int
     lib.crt_hip_probe_copy_f64.argtypes = [_vp, _vp, ctypes.c_size_t, _vp]
+    lib.crt_hip_probe_store_set_f64.restype = ctypes.c_int
+    lib.crt_hip_probe_store_set_f64.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, _vp]
     if lib.crt_hip_abi_version() != 2:
         raise HipLibraryMissing(f"{LIB_PATH}: ABI version mismatch, rebuild")
     _lib = lib

@@ -781,6 +781,30 @@ __global__ __launch_bounds__(256) void k_copy(d2* dst, const d2* src, size_t n2)
     __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
+// store-pattern probe: what the solve kernels' flush does and nothing else -- workgroup c writes, for column c of EVERY array of the
+// set, run after run of `run` doubles (T levels x nb bands) with 16-byte streaming stores, all arrays in step.  Run on a Plan's own
+// output set it measures the store rate that placement allows (the linear fill above writes one array, i.e. one memory class, at a time).
+struct StoreSetArgs {
+  double* p[8];
+  int na;
+  long long ncol, col;  // columns, doubles per column
+  int run;              // doubles per run (a multiple of 2)
+};
+__global__ __launch_bounds__(192) void k_store_set(StoreSetArgs a, double v) {
+  d2 t;
+  t.x = v;
+  t.y = v;
+  const long long c = blockIdx.x;
+  const long long base = c * a.col;
+  for (long long r0 = 0; r0 < a.col; r0 += a.run) {
+    const int n2 = (int)(min((long long)a.run, a.col - r0) >> 1);
+    for (int k = 0; k < a.na; ++k) {
+      d2* dst = reinterpret_cast<d2*>(a.p[k] + base + r0);
+      for (int i = threadIdx.x; i < n2; i += 192) __builtin_nontemporal_store(t, dst + i);
+    }
+  }
+}
+
 bool scheme_ok(int s) { return s >= 0 && s < CRT_NUM_SCHEMES; }
 
 }  // namespace
@@ -1135,6 +1159,24 @@ const char* crt_hip_last_kernel(void) { return last_kernel(); }
 int crt_hip_probe_fill_f64(double* dst, size_t n, double value, crt_stream_t stream) {
   if (!dst || n == 0 || (n & 1) || (reinterpret_cast<uintptr_t>(dst) & 15)) return CRT_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<d2*>(dst), n / 2, value);
+  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+}
+
+int crt_hip_probe_store_set_f64(double* const* arrays, int32_t narrays, int64_t ncol, int64_t col_doubles, int32_t run_doubles, double value,
+                                crt_stream_t stream) {
+  if (!arrays || narrays < 1 || narrays > 8 || ncol < 1 || ncol > 0x7fffffff || col_doubles < 2 || (col_doubles & 1) || run_doubles < 2 ||
+      (run_doubles & 1))
+    return CRT_ERR_BAD_ARG;
+  StoreSetArgs a;
+  for (int i = 0; i < narrays; ++i) {
+    if (!arrays[i] || (reinterpret_cast<uintptr_t>(arrays[i]) & 15)) return CRT_ERR_BAD_ARG;
+    a.p[i] = arrays[i];
+  }
+  a.na = narrays;
+  a.ncol = ncol;
+  a.col = col_doubles;
+  a.run = run_doubles;
+  hipLaunchKernelGGL(k_store_set, dim3((unsigned)ncol), dim3(192), 0, static_cast<hipStream_t>(stream), a, value);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 

@@ -273,6 +273,11 @@ const char* crt_hip_last_kernel(void);
 /* bandwidth probes used by bench.py to report a measured HBM ceiling next to the 8 TB/s spec */
 int crt_hip_probe_fill_f64(double* dst, size_t n, double value, crt_stream_t stream);
 int crt_hip_probe_copy_f64(double* dst, const double* src, size_t n, crt_stream_t stream);
+/* The flush of the solve kernels alone: workgroup c writes column c (col_doubles doubles) of all `narrays` arrays in step, run_doubles at a
+ * time (T levels x nb bands), with 16-byte streaming stores.  On a set from crt_hip_buffer_alloc_set it measures the store rate that
+ * placement allows; it OVERWRITES the arrays with `value`.  No counterpart in the reference. */
+int crt_hip_probe_store_set_f64(double* const* arrays, int32_t narrays, int64_t ncol, int64_t col_doubles, int32_t run_doubles, double value,
+                                crt_stream_t stream);
 
 #ifdef __cplusplus
 }

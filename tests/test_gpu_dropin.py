@@ -687,3 +687,26 @@ def test_plan_is_capturable_into_a_hip_graph(scheme, shape):
     torch.cuda.synchronize()
     for k in ref:
         assert torch.equal(plan.out[k], fresh[k]), k
+
+
+def test_store_set_probe():
+    """crt_hip_probe_store_set_f64 (the flush pattern of the solve kernels on a set of arrays): fills every array with the value, rejects bad
+    arguments."""
+    import ctypes
+
+    import torch
+
+    from crt1d_amd import _lib
+
+    lib = _lib.load()
+    ncol, col, run = 37, 60 * 38, 8 * 38
+    arrs = [torch.zeros(ncol * col, dtype=torch.float64, device="cuda") for _ in range(3)]
+    ptrs = (ctypes.c_void_p * 3)(*[a.data_ptr() for a in arrs])
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.crt_hip_probe_store_set_f64(ptrs, 3, ncol, col, run, 2.5, st) == 0
+    torch.cuda.synchronize()
+    for a in arrs:
+        assert bool((a == 2.5).all())
+    assert lib.crt_hip_probe_store_set_f64(ptrs, 0, ncol, col, run, 2.5, st) != 0
+    assert lib.crt_hip_probe_store_set_f64(ptrs, 3, ncol, col + 1, run, 2.5, st) != 0
+    assert lib.crt_hip_probe_store_set_f64(ptrs, 3, ncol, col, 3, 2.5, st) != 0
