@@ -543,31 +543,45 @@ __device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeC
   if (active) bandc[b] = st.band_const();
   const int K = S::rows(nz);
   double e, f;
-  st.first(rec, nz, e, f);  // (not kept: segment 0 starts from first() again -- one checkpoint pair per lane less, 5 KB at 300 bands)
-  for (int k = 0; k + 1 < K; ++k) {
+  // Forward sweep.  Checkpoints (every M levels) are kept for the segments 1 .. top-1 only: segment 0 restarts from first() and the TOP
+  // segment -- the first one to be substituted back -- is left in registers by the sweep itself, so it is neither stored nor recomputed
+  // (two checkpoint pairs per lane less = 10 KB of LDS at 300 bands; up to M - 1 level steps less before the first tile is handed over).
+  const int seg_top = (K - 1) / M, k_top = seg_top * M;
+  double be[M], bf[M];  // (e, f) of the levels of the segment being substituted back
+  st.first(rec, nz, e, f);
+  for (int k = 0; k < k_top; ++k) {
     st.advance(k, rec, nz, e, f);
-    if ((k + 1) % M == 0) {
+    if ((k + 1) % M == 0 && k + 1 < k_top) {
       const int sidx = (k + 1) / M - 1;  // checkpoint of segment sidx + 1
       ck[(2 * sidx) * nthr] = e;
       ck[(2 * sidx + 1) * nthr] = f;
     }
   }
+  be[0] = e;
+  bf[0] = f;
+#pragma unroll
+  for (int i = 1; i < M; ++i) {
+    be[i] = be[i - 1];
+    bf[i] = bf[i - 1];
+    if (k_top + i <= K - 1) st.advance(k_top + i - 1, rec, nz, be[i], bf[i]);
+  }
   int buf = 0;
-  for (int seg = (K - 1) / M; seg >= 0; --seg) {
+  for (int seg = seg_top; seg >= 0; --seg) {
     const int k0 = seg * M;
     const int kend = min(k0 + M - 1, K - 1);
-    double be[M], bf[M];
-    if (seg == 0) {
-      st.first(rec, nz, be[0], bf[0]);
-    } else {
-      be[0] = ck[(2 * (seg - 1)) * nthr];
-      bf[0] = ck[(2 * (seg - 1) + 1) * nthr];
-    }
+    if (seg != seg_top) {
+      if (seg == 0) {
+        st.first(rec, nz, be[0], bf[0]);
+      } else {
+        be[0] = ck[(2 * (seg - 1)) * nthr];
+        bf[0] = ck[(2 * (seg - 1) + 1) * nthr];
+      }
 #pragma unroll
-    for (int i = 1; i < M; ++i) {
-      be[i] = be[i - 1];
-      bf[i] = bf[i - 1];
-      if (k0 + i <= kend) st.advance(k0 + i - 1, rec, nz, be[i], bf[i]);
+      for (int i = 1; i < M; ++i) {
+        be[i] = be[i - 1];
+        bf[i] = bf[i - 1];
+        if (k0 + i <= kend) st.advance(k0 + i - 1, rec, nz, be[i], bf[i]);
+      }
     }
 #pragma unroll
     for (int i = M - 1; i >= 0; --i) {
@@ -794,7 +808,7 @@ int launch_pipe_generic(const SolveArgs& a, hipStream_t s, int nstore_waves) {
   const int K = S::rows(a.nz);
   PipeCfg cfg{};
   cfg.ncomp = ncomp;
-  cfg.nck = (K - 1) / M;  // checkpoints kept: segments 1 .. (K - 1) / M (segment 0 restarts from first())
+  cfg.nck = std::max((K - 1) / M - 1, 0);  // checkpoints kept: segments 1 .. top-1 (see tri_pipe_compute)
   cfg.off_bc = (a.reclen + 1) & ~1;
   cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
   cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
@@ -820,7 +834,7 @@ int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves, bool reg
   const int K = S::rows(a.nz);
   PipeCfg cfg{};
   cfg.ncomp = ncomp;
-  cfg.nck = (K - 1) / M;  // checkpoints kept: segments 1 .. (K - 1) / M (segment 0 restarts from first())
+  cfg.nck = std::max((K - 1) / M - 1, 0);  // checkpoints kept: segments 1 .. top-1 (see tri_pipe_compute)
   cfg.off_bc = (a.reclen + 1) & ~1;
   cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
   cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;

@@ -296,7 +296,7 @@ int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
   // store waves (nsw <= 0: automatic).  Measured (tools/ab_zqpa.py), two-kernel path -> fused with 2 / 3 / 4 / 5 store waves:
   //   1e4 x 300 x 60: 3.16 ms -> 1.51 / 1.34 / 1.67 / 1.60;  6e3 x 300 x 100 (one workgroup per CU): 3.16 -> 1.88 / 1.70 / 1.61 / 1.56;
   //   3e4 x 128 x 60: 3.47 -> 1.56 / 2.26 / 2.26 / 2.15
-  const size_t lds_doubles = (size_t)((a.reclen + 1) & ~1) + ((a.nb + 1) & ~1) + 2 * (size_t)(Mg / M) * ncomp + 4 * (size_t)T * a.nb + 6 * (size_t)a.nb;
+  const size_t lds_doubles = (size_t)((a.reclen + 1) & ~1) + ((a.nb + 1) & ~1) + 2 * (size_t)std::max(Mg / M - 1, 0) * ncomp + 4 * (size_t)T * a.nb + 6 * (size_t)a.nb;
   if (nsw <= 0) nsw = ncomp <= 64 ? 1 : ncomp <= 128 ? 2 : (lds_doubles * sizeof(double) > MAX_WG_LDS / 2 ? 5 : 3);
   if (ncomp + 64 * nsw > 1024) nsw = (1024 - ncomp) / 64;
   if (nsw < 1) return CRT_ERR_UNSUPPORTED;
@@ -306,7 +306,7 @@ int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
   for (int i = 0; i < 7; ++i) g.o[i] = nullptr;
   PipeCfg cfg{};
   cfg.ncomp = ncomp;
-  cfg.nck = Mg / M;  // K = Mg + 1 rows; segment 0 restarts from first(), its checkpoint is not kept
+  cfg.nck = std::max(Mg / M - 1, 0);  // K = Mg + 1 rows; checkpoints for the segments 1 .. top-1 (see tri_pipe_compute)
   cfg.off_bc = (a.reclen + 1) & ~1;
   cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
   cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
