@@ -285,7 +285,7 @@ __global__ __launch_bounds__(MAXT) void k_zqpa_pipe(SolveArgs a, PipeCfg cfg) {
 
 // returns CRT_ERR_UNSUPPORTED when the shape does not fit (caller falls back to the two-kernel path)
 template <typename TIO, int M, int T>
-int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
+int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw, size_t lds_cap = MAX_WG_LDS) {
   if (a.nb < (a.tune[12] > 0 ? a.tune[12] : 16)) return CRT_ERR_UNSUPPORTED;  // (tune 12: smallest nb, as for the other pipelines)
   const bool flat = a.nb % 2;  // odd nb: rows are not pair-aligned -> flat store role
   if (flat && a.tune[13] == 1) return CRT_ERR_UNSUPPORTED;
@@ -314,7 +314,7 @@ int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw) {
   cfg.nz_out = a.nz;
   for (int i = 0; i < 4; ++i) cfg.out[i] = a.o[i];
   const size_t sh = ((size_t)cfg.off_halo + 2 * 3 * a.nb) * sizeof(double);
-  if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
+  if (sh > lds_cap) return CRT_ERR_UNSUPPORTED;
   auto go = [&](auto kern) {
     if (sh > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
@@ -334,12 +334,19 @@ int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s) {
   if (g_tri_tune[2] != 1 || a.f32) {  // fused interpolation first (tune key 10 = 1: the two-kernel path with workspace scratch)
     const int nsw = g_tri_tune[3];
     int st;
+    // two workgroups per CU first (half of the LDS each): M = 16, T = 4, or -- above ~85 levels at 300 bands -- tiles of 3 levels
+    // (M = 15), which is what brings 100 levels from 84 KB to 74 KB; then whatever fits at all
+    constexpr size_t HALF = MAX_WG_LDS / 2;
     if (a.f32) {
-      st = launch_zqpa_fused<float, 16, 4>(a, s, nsw);
+      st = launch_zqpa_fused<float, 16, 4>(a, s, nsw, HALF);
+      if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<float, 15, 3>(a, s, nsw, HALF);
+      if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<float, 16, 4>(a, s, nsw);
       if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<float, 12, 4>(a, s, nsw);
       return st;  // f32 storage exists in the fused kernel only (the two-kernel path keeps its computational-grid scratch in fp64)
     }
-    st = launch_zqpa_fused<double, 16, 4>(a, s, nsw);
+    st = launch_zqpa_fused<double, 16, 4>(a, s, nsw, HALF);
+    if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<double, 15, 3>(a, s, nsw, HALF);
+    if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<double, 16, 4>(a, s, nsw);
     if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<double, 12, 4>(a, s, nsw);
     if (st != CRT_ERR_UNSUPPORTED) return st;
   }
