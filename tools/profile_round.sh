@@ -43,6 +43,8 @@ CASES=(
 "epilogue|wf|$R/tools/epilogue_bench.py 10000 300 60"
 "epilogue_nb38|wfsqi|$R/tools/epilogue_bench.py 100000 38 100"
 "zq_pa_nb38|wfsq|$R/bench.py --scheme zq_pa --nb 38 --nz 100 --ncol 100000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
+"zq_pa_nz100|wf|$R/bench.py --scheme zq_pa --nz 100 --ncol 6000 $B"
+"n79_nz100|wf|$R/bench.py --scheme n79 --nz 100 --ncol 6000 $B"
 "zq_pa_nb107|wfsq|$R/bench.py --scheme zq_pa --nb 107 --ncol 30000 $B"
 )
 for entry in "${CASES[@]}"; do
