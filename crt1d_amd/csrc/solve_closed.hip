@@ -525,6 +525,10 @@ __global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int c0 = blockIdx.x * CB;
   const int ncb = min(CB, a.ncol - c0);  // columns actually present in this workgroup
+  const int cl = tid / nb, b = tid - cl * nb;
+  const bool active = cl < ncb;
+  BandIn bin = {};  // requested together with the records (as in k_pipe): one round trip before the first level instead of two
+  if (active) bin = load_band<TIO>(a, c0 + cl, b, S::SOIL);
   // stage the column records (contiguous in the workspace)
   {
     const double* src = a.ws + (long long)c0 * a.reclen;
@@ -533,11 +537,9 @@ __global__ __launch_bounds__(MAXT) void k_tile(SolveArgs a, TileCfg cfg) {
   }
   __syncthreads();
   TIO* tile = reinterpret_cast<TIO*>(lds + cfg.rec_dbl);  // [NARR][CB][T][nb]
-  const int cl = tid / nb, b = tid - cl * nb;
-  const bool active = cl < ncb;
   const double* rec = lds + (active ? cl : 0) * a.reclen;
   S st;
-  if (active) st.init(rec, load_band<TIO>(a, c0 + cl, b, S::SOIL), a);
+  if (active) st.init(rec, bin, a);
   const int colrun = T * nb;  // elements per (array, column) slot of the tile
   // FUSED flush (one column per workgroup, nb a multiple of the 16-B vector width, 16-B aligned outputs): a vector never
   // straddles a row, so thread -> (row offset, vector within the row) is fixed for the whole kernel and all NARR arrays
