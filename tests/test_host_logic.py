@@ -175,3 +175,36 @@ def test_band_partition_deals_pairs():
     assert [band_block_range(9, k, 2) for k in range(2)] == [(0, 5), (5, 9)]
     assert [band_block_range(10, k, 8)[1] - band_block_range(10, k, 8)[0] for k in range(8)] == [2, 2, 1, 1, 1, 1, 1, 1]
     assert [block_range(7, k, 3) for k in range(3)] == [(0, 3), (3, 5), (5, 7)]
+
+
+def test_canopy_derive_is_pure_and_validates():
+    """crt1d_amd.canopy.derive (the validation / derivation of model.py:222-294 as a pure function): does not touch its argument, derives
+    the documented entries, and refuses the cases the reference asserts on."""
+    from crt1d_amd import canopy
+    from crt1d_amd.cases import load_default_case
+
+    p = load_default_case(nlayers=12)
+    before = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+    d = canopy.derive(p)
+    assert set(p) == set(before) and all(np.array_equal(p[k], before[k]) if isinstance(before[k], np.ndarray) else p[k] is before[k] or p[k] == before[k] for k in before)
+    assert set(d) == {"lai_tot", "lai_eff", "dlai", "dlai_eff", "zm", "dz", "mu", "wle", "K_b_fn", "G", "K_b"}
+    np.testing.assert_allclose(d["dlai"].sum(), p["lai"][0])
+    np.testing.assert_allclose(d["zm"], 0.5 * (p["z"][:-1] + p["z"][1:]))
+    np.testing.assert_allclose(np.diff(d["wle"]), p["dwl"])
+    assert d["K_b"] == pytest.approx(d["G"] / np.cos(p["psi"]))
+    assert canopy.sizes(p) == (12, p["wl"].size)
+    for bad in (dict(lai=p["lai"][::-1]), dict(z=p["z"][::-1]), dict(lai=p["lai"] + 0.1), dict(dwl=p["dwl"][:-1]), dict(wl_leafsoil=p["wl"][:-1])):
+        with pytest.raises(canopy.CanopyInputError):
+            canopy.derive({**p, **bad})
+    # CanopyInputError is caught by handlers written for the reference's AssertionError as well as by ValueError handlers
+    assert issubclass(canopy.CanopyInputError, AssertionError) and issubclass(canopy.CanopyInputError, ValueError)
+    q = dict(p)
+    del q["psi"]
+    with pytest.raises(canopy.CanopyInputError, match="required key psi"):
+        canopy.derive(q)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        canopy.derive({**p, "mu": 0.123})
+        canopy.derive({**p, "wl_leafsoil": p["wl"] * 1.01})
+        msgs = " ".join(str(x.message) for x in w)
+    assert "not consistent with provided `psi`" in msgs and "appear to be incompatible" in msgs
