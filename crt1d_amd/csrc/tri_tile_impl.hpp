@@ -769,8 +769,10 @@ __device__ __forceinline__ void tri_pipe_store(const SolveArgs& a, const PipeCfg
 // register-staged M = 16 form (levels above ~80) takes 130 and only ONE workgroup stays resident: zq at 6000 x 300 x 100
 // 1.74 ms (0.73 of the peak) -> 1.55 ms (0.82) with the cap (12 bytes of scratch per lane).  profiles/r02/kernel_resources.txt lists
 // every kernel's registers / occupancy (hipcc -Rpass-analysis=kernel-resource-usage).
+// RS = 2 is the narrow-spectrum form (one compute + one store wave per column, two band pairs staged per store thread): five waves per
+// SIMD, i.e. ten of these two-wave workgroups per CU instead of eight.
 template <class S, typename TIO, int M, int T, int MAXT, int RS>
-__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4))) void k_tri_pipe(SolveArgs a, PipeCfg cfg) {
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(RS == 2 ? 5 : 4))) void k_tri_pipe(SolveArgs a, PipeCfg cfg) {
   static_assert(M % T == 0, "tile height must divide the checkpoint spacing");
   extern __shared__ double lds[];
   {
@@ -840,15 +842,20 @@ int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves, bool reg
   cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
   const size_t sh = ((size_t)cfg.off_tile + (size_t)(regstage ? 1 : 2) * S::NST * T * a.nb) * sizeof(double);
   if (sh > (regstage ? MAX_WG_LDS / 2 : MAX_WG_LDS)) return CRT_ERR_UNSUPPORTED;  // register staging only pays with 2 WG/CU
+  // (M = 8 only: at M = 12 the n79 compute role does not fit the 96 registers of five waves per SIMD and spills -- 3.45 -> 4.51 ms)
+  const bool narrow_rs = T == 4 && M == 8 && regstage && nthr <= 512 && T * (a.nb / 2) <= 2 * 64 * nstore_waves && a.tune[2] != 16;
   auto go = [&](auto kern) {
     if (sh > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, cfg);
     note_kernel("k_tri_pipe<%s,%s> %s M=%d T=%d store_waves=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32",
-                regstage ? "register-staged" : "double-buffered", M, T, nstore_waves, sh);
+                regstage ? (narrow_rs ? "register-staged(2 pairs)" : "register-staged") : "double-buffered", M, T, nstore_waves, sh);
     return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
   };
+  if constexpr (T == 4 && M == 8) {  // narrow spectra: two staged pairs per store thread cover the tile
+    if (narrow_rs) return go(k_tri_pipe<S, TIO, M, T, 512, 2>);  // (crt_options.tune[2] = 16 keeps the four-pair form: A/B)
+  }
   if (regstage) return nthr <= 512 ? go(k_tri_pipe<S, TIO, M, T, 512, PIPE_RS>) : go(k_tri_pipe<S, TIO, M, T, 1024, PIPE_RS>);
   return nthr <= 512 ? go(k_tri_pipe<S, TIO, M, T, 512, 0>) : go(k_tri_pipe<S, TIO, M, T, 1024, 0>);
 }
@@ -939,7 +946,10 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 10
       } else {
         const int pp_n79[3][2] = {{12, 4}, {16, 4}, {8, 4}};
         const int pp_zq[3][2] = {{8, 4}, {12, 4}, {16, 4}};
-        const int (*pp)[2] = S::NOUT == 6 ? pp_n79 : pp_zq;
+        // narrow spectra (one compute wave): M = 8 has the two-pair store role and five or six waves per SIMD (tools/ab_narrow_rs.py:
+        // n79 1.5e5 x 38 x 60 3.14 -> 3.04 ms, 2e5 x 16 x 60 2.82 -> 2.61; zq 3.37 -> 3.11, 3.22 -> 2.92); above ~80 levels its
+        // checkpoints cost n79 the occupancy again (1e5 x 38 x 100: 3.43 with M = 16 against 3.50)
+        const int (*pp)[2] = (S::NOUT == 6 && !(nthr == 64 && a.nz <= 80)) ? pp_n79 : pp_zq;
         for (int i = 0; i < 3 && st == CRT_ERR_UNSUPPORTED && try_rs; ++i) st = launch_pipe<S, TIO>(a, s, pp[i][0], pp[i][1], nsw_rs, true);
         for (int i = 0; i < 3 && st == CRT_ERR_UNSUPPORTED && try_db; ++i) st = launch_pipe<S, TIO>(a, s, pp[i][0], pp[i][1], nsw, false);
       }
