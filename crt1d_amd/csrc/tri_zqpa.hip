@@ -344,7 +344,11 @@ int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s) {
       if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<float, 12, 4>(a, s, nsw);
       return st;  // f32 storage exists in the fused kernel only (the two-kernel path keeps its computational-grid scratch in fp64)
     }
-    st = launch_zqpa_fused<double, 16, 4>(a, s, nsw, HALF);
+    st = CRT_ERR_UNSUPPORTED;
+    // narrow spectra (one compute wave per column): M = 12 needs 92 registers, five waves per SIMD instead of four (1e5 x 38 x 100:
+    // 3.74 -> 3.64 ms, 2e5 x 16 x 60 3.23 -> 3.16; at 62 bands the other way, 2.61 -> 2.64).  (tune key 8 = 16 keeps M = 16.)
+    if (a.nb <= 48 && g_tri_tune[0] != 16) st = launch_zqpa_fused<double, 12, 4>(a, s, nsw, HALF);
+    if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<double, 16, 4>(a, s, nsw, HALF);
     if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<double, 15, 3>(a, s, nsw, HALF);
     if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<double, 16, 4>(a, s, nsw);
     if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused<double, 12, 4>(a, s, nsw);
