@@ -803,7 +803,9 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
     const bool fused = pfused;  // (shadows k_tile's flag inside this block)
     const int pcomp = ((nb + 63) / 64) * 64;
     const size_t plevel = (size_t)S::NARR * nb * sizeof(TIO);
-    int nsw = g_tune[3] > 0 ? g_tune[3] : (pcomp <= 64 && (S::HEAVY_INIT || nb < 16) ? 1 : pcomp <= 128 ? 2 : 3);
+    // one compute wave (nb <= 64): one store wave keeps up with it and leaves more columns resident (tools/ab_2s_narrow.py, streaming
+    // stores: 2e5 x 38 x 60 2s 2.53 -> 2.47 ms, g77 4.53 -> 4.27; 4e5 x 16 x 60 2s 3.39 -> 2.87, g77 4.52 -> 4.20; 4s already had one)
+    int nsw = g_tune[3] > 0 ? g_tune[3] : (pcomp <= 64 ? 1 : pcomp <= 128 ? 2 : 3);
     if (pcomp + 64 * nsw > 1024) nsw = (1024 - pcomp) / 64;
     // Two tile buffers of up to 8 levels, line-aligned runs when they fit, at least two workgroups per CU -- and about four
     // for a scheme with a heavy per-band set-up when the spectrum is narrow enough to allow it.  Measured (tools/ab_shapes.py,
@@ -820,6 +822,7 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
     // (3e4 x 107 x 60, k_tile -> T=8 -> T=4: 2s 1.268 -> 1.285 -> 1.085 ms, bl 1.174 -> 1.136 -> 1.066, g77 2.174 -> 1.957 -> 1.861)
     if (!fused && pcomp <= 128 && budget > 32 * 1024) budget = 32 * 1024;
     int Tmax = (int)std::min<size_t>(8, budget / (2 * plevel));
+    if (fused && pcomp <= 64 && nb >= 32 && Tmax > 4) Tmax = 4;  // 32..64 bands: tiles of 4 levels (same measurement: 38 bands, T = 8 -> 4: 2s 2.52 -> 2.47, g77 4.41 -> 4.27)
     if (Tmax < 4 && 2 * plevel * 4 <= target) Tmax = 4;  // not below 4 levels while two workgroups still fit (g77 at nb = 107: T=2 1.96 ms, T=4 1.87)
     int Tp = Ta <= Tmax ? (Tmax / Ta) * Ta : Tmax;
     if (g_tune[4] > 0) Tp = g_tune[4];
