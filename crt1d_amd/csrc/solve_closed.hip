@@ -805,9 +805,9 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
     const size_t plevel = (size_t)S::NARR * nb * sizeof(TIO);
     // one compute wave (nb <= 64): one store wave keeps up with it and leaves more columns resident (tools/ab_2s_narrow.py, streaming
     // stores: 2e5 x 38 x 60 2s 2.53 -> 2.47 ms, g77 4.53 -> 4.27; 4e5 x 16 x 60 2s 3.39 -> 2.87, g77 4.52 -> 4.20; 4s already had one)
-    // (a scheme with a heavy per-band set-up -- 4s -- also takes one store wave with two compute waves: tools/ab_closed_107.py, 3e4 x 107 x 60
-    // 1.09 -> 1.03 ms, 25000 x 128 x 60 0.95 -> 0.91)
-    int nsw = g_tune[3] > 0 ? g_tune[3] : (pcomp <= 64 || (S::HEAVY_INIT && pcomp <= 128) ? 1 : pcomp <= 128 ? 2 : 3);
+    // (4s -- heavy per-band set-up -- also takes one store wave with two compute waves and the whole-line generic flush:
+    // tools/ab_closed_107.py, 3e4 x 107 x 60 1.09 -> 1.03 ms; not with the fused flush: 25000 x 128 x 60 0.95 -> 0.99)
+    int nsw = g_tune[3] > 0 ? g_tune[3] : (pcomp <= 64 || (S::HEAVY_INIT && pcomp <= 128 && !fused) ? 1 : pcomp <= 128 ? 2 : 3);
     if (pcomp + 64 * nsw > 1024) nsw = (1024 - pcomp) / 64;
     // Two tile buffers of up to 8 levels, line-aligned runs when they fit, at least two workgroups per CU -- and about four
     // for a scheme with a heavy per-band set-up when the spectrum is narrow enough to allow it.  Measured (tools/ab_shapes.py,
