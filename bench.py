@@ -277,6 +277,9 @@ def parse_args(argv):
     ap.add_argument("--ncol", type=int, default=None, help="columns PER GPU (column partition; default 10000) or in TOTAL (band partition; default 100000)")
     ap.add_argument("--nb", type=int, default=300)
     ap.add_argument("--nz", type=int, default=None)
+    ap.add_argument("--ragged", action="store_true", help="columns with NON-uniform dLAI (SURVEY 8(d): lai = LAI (1 - linspace(0,1,nz)**gamma), gamma ~ U(0.5, 2)); "
+                    "the default linspace columns are what every reference LAI generator makes, but any strictly decreasing lai is legal input "
+                    "(crt1d/model.py:240-246)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
                     help="storage type of spectra/profiles; arithmetic is fp64 either way (f32 = config 5 variant, not the headline)")
     ap.add_argument("--variant", default="profiles", choices=["profiles", "integrated"],
@@ -409,7 +412,7 @@ def main():
 
         if f32:
             raise SystemExit("--partition band runs the fp64 path")
-        d = synth.make_columns(ncol, nb, nz, seed=1234)  # the SAME columns on every rank: K0 is replicated, the bands are sharded
+        d = synth.make_columns(ncol, nb, nz, seed=1234, uniform_dlai=not a.ragged)  # the SAME columns on every rank: K0 is replicated, the bands are sharded
         cols = batched.Columns.from_host(d, dev)
         bands = batched.Bands.from_host(d, dev)
         bw = torch.as_tensor(spectra.band_weights(d["wle"])).to(dev)
@@ -468,7 +471,7 @@ def main():
         nb_kernel = nb_local
     else:
         # ---------------------------------------------------------------- column partition: the headline
-        d = synth.make_columns(ncol, nb, nz, seed=1234 + rank)  # this rank's column block: its own seed -> distinct columns of one grid
+        d = synth.make_columns(ncol, nb, nz, seed=1234 + rank, uniform_dlai=not a.ragged)  # this rank's column block: its own seed -> distinct columns of one grid
         cols = batched.Columns.from_host(d, dev)
         if f32:
             import numpy as np
@@ -695,6 +698,7 @@ def main():
                          + ", fp64" + (" (BASELINE.json configs[1] shape)" if (scheme, ncol, nb, nz, band) == ("2s", 10000, 300, 60, False) else "")
                          + (" (BASELINE.json configs[3] shape)" if (scheme, ncol, nb, nz, band) == ("zq", 100000, 300, 100, True) else "")),
             "scheme": scheme, ("ncol_total" if band else "ncol_per_gpu"): ncol, "nb": nb, "nz": nz,
+            "dlai": "ragged (lai = LAI (1 - x**gamma), gamma ~ U(0.5, 2))" if a.ragged else "uniform (linspace, as every reference LAI generator)",
             "partition": extra.pop("partition", "column blocks, no collective"),
             "step": (("K0 column precompute + solve kernel via crt_hip_%s_f64" % scheme) + (" + crt_hip_absorb_bandsum_f64 + all-reduce, per column tile" if band else ""))
                     if a.variant == "profiles" else ("K0 + crt_hip_integrated_f64 (no profiles written)" + (" + all-reduce, per column tile" if band else "")),
