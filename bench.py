@@ -73,6 +73,8 @@ def _cpu_worker(args):
         kw.pop("soil_r")
     fn = O.SOLVERS[scheme]
     fn(oc, **kw)
+    if sys.stdin.readline().strip() != "go":  # released by run_cpu_workers (EOF = the parent gave up)
+        raise SystemExit(3)
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < budget_s and n < 400:
@@ -81,27 +83,44 @@ def _cpu_worker(args):
     return n * chunk * nb, time.perf_counter() - t0
 
 
-def cpu_baseline_all_cores(scheme, nb, nz, nproc, budget_s=8.0):
-    """Aggregate oracle rate of `nproc` independent host processes (one per core).
-    Plain subprocesses of this script (`--cpu-worker`), each with a hard timeout: they import NumPy only, never the GPU."""
+def spawn_cpu_workers(scheme, nb, nz, nproc, budget_s=8.0):
+    """Start `nproc` host worker processes of this script (`--cpu-worker`) that import NumPy only, never the GPU, and then BLOCK on their
+    stdin until `run_cpu_workers` tells them to go.  Called before this process has imported torch or touched the GPU (process creation
+    from a GPU-initialised parent is what the pool's rules warn about), while the timing itself happens after the GPU work is over."""
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker"]
-    procs = [subprocess.Popen(cmd + [scheme, str(nb), str(nz), str(1000 + i), str(budget_s)], stdout=subprocess.PIPE,
-                              stderr=subprocess.DEVNULL, text=True, env=env) for i in range(nproc)]
+    return [subprocess.Popen(cmd + [scheme, str(nb), str(nz), str(1000 + i), str(budget_s)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, text=True, env=env) for i in range(nproc)]
+
+
+def stop_cpu_workers(procs):
+    for q in procs or []:
+        if q.poll() is None:
+            q.kill()
+    for q in procs or []:
+        try:
+            q.wait(timeout=10)
+        except Exception:
+            pass
+
+
+def run_cpu_workers(procs, budget_s=8.0):
+    """Aggregate oracle rate of the waiting worker processes (one per core): release them together, add their rates."""
     total = 0.0
     deadline = time.time() + budget_s + 90
-    for p in procs:
-        try:
+    try:
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        for p in procs:
             out, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
             solves, secs = out.split()[-2:]
             total += float(solves) / float(secs)
-        except Exception:
-            for q in procs:
-                if q.poll() is None:
-                    q.kill()
-            raise
+    except Exception:
+        stop_cpu_workers(procs)
+        raise
     return total
 
 
@@ -149,8 +168,9 @@ def reference_shaped_baseline(scheme, nb, nz, budget_s=6.0):
     return out
 
 
-def cpu_baseline(scheme, nb, nz, budget_s=15.0):
-    """Oracle (NumPy port of the reference algorithm) on the host: solves/s on 1 core and on the box's cores, bounded sample."""
+def cpu_baseline(scheme, nb, nz, budget_s=15.0, workers=None):
+    """Oracle (NumPy port of the reference algorithm) on the host: solves/s on 1 core and on the box's cores, bounded sample.
+    `workers`: the processes `spawn_cpu_workers` started before the GPU was initialised."""
     from crt1d_amd import synth
     from oracle import crt_oracle as O
 
@@ -171,11 +191,11 @@ def cpu_baseline(scheme, nb, nz, budget_s=15.0):
         if el > budget_s * 0.5 or n >= 400:
             break
     one_core = n * chunk * nb / el
-    nproc = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
+    nproc = len(workers) if workers else 1
     all_cores = None
     if nproc > 1:
         try:
-            all_cores = cpu_baseline_all_cores(scheme, nb, nz, nproc)
+            all_cores = run_cpu_workers(workers)
         except Exception as e:  # never lose the bench line over the baseline
             print(f"all-core CPU baseline failed: {e!r}", file=sys.stderr)
     sample = (f"oracle.solve_{scheme} (NumPy port of the reference algorithm, vectorised over {chunk}-column chunks), {nb} bands x {nz} "
@@ -188,6 +208,82 @@ def cpu_baseline(scheme, nb, nz, budget_s=15.0):
     except Exception as e:
         print(f"reference-shaped CPU baseline failed: {e!r}", file=sys.stderr)
     return out
+
+
+def oracle_check(scheme, d, out, ncol, lo=0, hi=None, nsample=8, f32=False, c0=0):
+    """Self-check of the TIMED output buffers (outside the timed region): `nsample` columns (first, last, random) of the profiles the
+    bench just wrote, against the oracle on the same inputs.  The oracle is test infrastructure and is used here only as the checker.
+    `d`: the host inputs of all `ncol` columns; `out`: the device profiles (ncol_out, nz | nz-1, hi - lo); [lo, hi): this rank's bands."""
+    import numpy as np
+
+    from oracle import crt_oracle as O
+
+    rng = np.random.default_rng(2718)
+    n_out = next(iter(out.values())).shape[0]
+    if n_out <= nsample:
+        idx = np.arange(n_out)
+    else:
+        idx = np.unique(np.r_[0, n_out - 1, 1 + rng.choice(n_out - 2, nsample - 2, replace=False)])
+    sub = {k: (v[c0 + idx] if hasattr(v, "shape") and v.shape[:1] == (ncol,) else v) for k, v in d.items()}
+    if f32:
+        sub = {k: (v.astype(np.float32).astype(np.float64) if k in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r") else v) for k, v in sub.items()}
+    oc = O.Columns(sub["psi"], sub["lai"], mla=sub["mla"], g_kind=sub["g_kind"], g_param=sub["g_param"])
+    kw = {k: sub[k][:, lo:hi] for k in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r")}
+    if scheme == "bl":
+        kw.pop("soil_r")
+    ref = O.SOLVERS[scheme](oc, **kw)
+    worst_p, worst_e, finite = 0.0, 0.0, True
+    ti = None
+    for k, v in out.items():
+        import torch
+
+        if ti is None:
+            ti = torch.as_tensor(idx, device=v.device)
+        g = v.index_select(0, ti).double().cpu().numpy()
+        r = ref[k]
+        finite = finite and bool(np.isfinite(g).all())
+        scale = np.abs(r).max(axis=1, keepdims=True)
+        scale = np.where(scale == 0, 1.0, scale)
+        worst_p = max(worst_p, float(np.max(np.abs(g - r) / scale)))
+        den = np.maximum(np.abs(r), (1e-6 if f32 else 1e-9) * scale)
+        worst_e = max(worst_e, float(np.max(np.abs(g - r) / den)))
+    # bars: fp64 profiles 1e-9 of the profile maximum / 1e-6 elementwise (north_star); f32 storage one float rounding
+    bar_p, bar_e = (2.0 ** -23, 2.0 ** -23) if f32 else (1e-9, 1e-6)
+    return {"against": f"oracle.solve_{scheme} on the same inputs", "columns": [int(c0 + i) for i in idx], "bands": [lo, hi if hi is not None else "all"],
+            "arrays": sorted(out), "max_rel_profile": worst_p, "max_rel_elem": worst_e, "finite": finite,
+            "bar_profile": bar_p, "bar_elem": bar_e, "ok": bool(finite and worst_p <= bar_p and worst_e <= bar_e)}
+
+
+def oracle_check_integrated(scheme, d, res, ncol, band_w, nsample=8):
+    """The band-integrated results of the timed step (after the all-reduce, all bands) on `nsample` columns against the oracle:
+    solve -> layer absorption (model.py:573-647) -> sum over bands with the weights (diagnostics.py:81)."""
+    import numpy as np
+    import torch
+
+    from oracle import crt_oracle as O
+
+    rng = np.random.default_rng(31415)
+    idx = np.arange(ncol) if ncol <= nsample else np.unique(np.r_[0, ncol - 1, 1 + rng.choice(ncol - 2, nsample - 2, replace=False)])
+    sub = {k: (v[idx] if hasattr(v, "shape") and v.shape[:1] == (ncol,) else v) for k, v in d.items()}
+    oc = O.Columns(sub["psi"], sub["lai"], mla=sub["mla"], g_kind=sub["g_kind"], g_param=sub["g_param"])
+    kw = {k: sub[k] for k in ("I_dr0", "I_df0", "leaf_r", "leaf_t", "soil_r")}
+    if scheme == "bl":
+        kw.pop("soil_r")
+    sol = O.SOLVERS[scheme](oc, **kw)
+    ab = O.calc_absorption(oc, sol, leaf_r=sub["leaf_r"], leaf_t=sub["leaf_t"])
+    w = np.asarray(band_w)  # (ng, nb)
+    ti = torch.as_tensor(idx, device=res["aI"].device)
+    worst = 0.0
+    for k in ("aI", "aI_sl", "aI_sh"):
+        ref = ab[k] @ w.T  # (n, nz-1, ng)
+        g = res[k].index_select(0, ti).cpu().numpy()
+        worst = max(worst, float(np.max(np.abs(g - ref) / np.abs(ref).max(axis=1, keepdims=True))))
+    top_d = (sol["I_dr"][:, -1] + sol["I_df_d"][:, -1]) @ w.T
+    top_u = sol["I_df_u"][:, -1] @ w.T
+    refl = res["reflectance"].index_select(0, ti).cpu().numpy()
+    worst_r = float(np.max(np.abs(refl - top_u / top_d) / np.abs(top_u / top_d)))
+    return {"against": f"oracle.solve_{scheme} + calc_absorption + band sums, all bands (after the all-reduce)", "columns": [int(i) for i in idx],
+            "max_rel_absorption_profile": worst, "max_rel_reflectance": worst_r, "bar": 1e-9, "ok": bool(worst <= 1e-9 and worst_r <= 1e-9)}
 
 
 def load_pmc_traffic(kernel, shape):
@@ -288,6 +384,7 @@ def parse_args(argv):
     ap.add_argument("--compare-plain", action="store_true", help="also time the solve kernel on torch.empty outputs (roofline.kernel_ms_avg_torch_empty_outputs); "
                     "off by default so that a rocprofv3 average of the default command describes ONE allocation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle self-check of the timed output buffers")
     ap.add_argument("--no-pcie", action="store_true", help="skip the H2D + step + D2H measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; 'gloo' + --share-device rehearses the N>1 code path on a one-GPU box")
@@ -335,6 +432,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    cpu_workers = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.launch_check:
+        nproc = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
+        if nproc > 1:  # started NOW, before torch is imported or the GPU touched; they idle until the GPU work is over
+            cpu_workers = spawn_cpu_workers(a.scheme, a.nb, a.nz, nproc)
 
     import torch
     import torch.distributed as dist
@@ -405,6 +507,7 @@ def main():
     f32 = a.dtype == "f32"
     band = a.partition == "band"
     extra = {}
+    check, check_int = None, None
     if band:
         # ---------------------------------------------------------------- band partition: BASELINE configs[3]
         from crt1d_amd import dist as cdist
@@ -464,8 +567,20 @@ def main():
                 "semantics": "sum over bands of w * X (crt1d/diagnostics.py:81); reflectance = reflected / incoming after the reduce (:510-511)",
             },
             "kernels_per_rank": knames,
-            "check": {"mean_solar_reflectance": float(ref[:, 2].mean()), "finite": bool(torch.isfinite(ref).all())},
+            "check_sums": {"mean_solar_reflectance": float(ref[:, 2].mean()), "finite": bool(torch.isfinite(ref).all())},
         }
+        if not a.no_check:
+            # self-check of the timed step's buffers: (i) the profiles the LAST column tile left in the (shared) output set, this rank's bands;
+            # (ii) the integrated results of ALL columns after the all-reduce (rank 0: they are complete on every rank)
+            try:
+                lt = plan.tiles[-1]
+                if a.variant == "profiles" and lt.profiles is not None:
+                    check = oracle_check(scheme, d, lt.profiles, ncol, plan.band_range[0], plan.band_range[1], c0=lt.clo)
+                else:
+                    check = None
+                check_int = oracle_check_integrated(scheme, d, res_holder["r"], ncol, spectra.band_weights(d["wle"])) if rank == 0 else None
+            except Exception as e:  # the check must never cost the bench line; a failure is reported in it
+                check, check_int = {"ok": False, "error": repr(e)}, None
         main_plan = plan.tiles[0].kernel_plan
         ncol_kernel = plan.tiles[0].chi - plan.tiles[0].clo
         nb_kernel = nb_local
@@ -473,6 +588,7 @@ def main():
         # ---------------------------------------------------------------- column partition: the headline
         d = synth.make_columns(ncol, nb, nz, seed=1234 + rank, uniform_dlai=not a.ragged)  # this rank's column block: its own seed -> distinct columns of one grid
         cols = batched.Columns.from_host(d, dev)
+        d64_host = d
         if f32:
             import numpy as np
 
@@ -487,6 +603,16 @@ def main():
             main_plan = batched.Plan(scheme, cols, bands, placement=a.placement)
         blocks = timed_blocks(lambda: main_plan())
         solves_per_step = ncol * nb * world
+        if not a.no_check:
+            try:  # the buffers as the timed region left them, before any probe overwrites them
+                if a.variant == "profiles":
+                    check = oracle_check(scheme, d64_host if f32 else d, main_plan.out, ncol, f32=f32)
+                elif rank == 0:
+                    r_int = dict(main_plan.out)
+                    r_int["reflectance"] = r_int["totals"][..., 1] / r_int["totals"][..., 0]
+                    check_int = oracle_check_integrated(scheme, d, r_int, ncol, spectra.band_weights(d["wle"]))
+            except Exception as e:
+                check = {"ok": False, "error": repr(e)}
         ncol_kernel, nb_kernel = ncol, nb
         if pg:
             # RCCL evidence for the scaling runs (outside the timed region, never part of `value`): did the collective see N ranks,
@@ -711,7 +837,18 @@ def main():
     if pcie is not None:
         out["pcie_inclusive"] = pcie
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(scheme, nb, nz, a.cpu_budget)
+        out["cpu_baseline"] = cpu_baseline(scheme, nb, nz, a.cpu_budget, cpu_workers)
+    stop_cpu_workers(cpu_workers)
+    if not a.no_check:  # (rank-independent condition: every rank takes part in the gather)
+        checks = [check]
+        if pg:  # every rank checked its own buffers: rank 0 reports all of them
+            checks = [None] * world
+            dist.all_gather_object(checks, check)
+        out["check"] = checks[0] if len(checks) == 1 else {"ok": all(c is None or c.get("ok") for c in checks), "per_rank": checks}
+        if checks == [None]:
+            out.pop("check")
+        if check_int is not None:
+            out["check_integrated"] = check_int
     if pg:
         dist.barrier()
         dist.destroy_process_group()

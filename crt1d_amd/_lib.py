@@ -102,6 +102,7 @@ EXPORTS = [
     "crt_hip_buffer_alloc",
     "crt_hip_buffer_free",
     "crt_hip_buffer_trim",
+    "crt_hip_buffer_set_retain",
     "crt_hip_buffer_describe",
     "crt_hip_buffer_stats",
     "crt_hip_last_kernel",
@@ -186,6 +187,8 @@ def load():
     lib.crt_hip_buffer_alloc_set.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_void_p)]
     lib.crt_hip_buffer_trim.restype = ctypes.c_int
     lib.crt_hip_buffer_trim.argtypes = []
+    lib.crt_hip_buffer_set_retain.restype = ctypes.c_int
+    lib.crt_hip_buffer_set_retain.argtypes = [ctypes.c_size_t]
     lib.crt_hip_buffer_describe.restype = ctypes.c_int
     lib.crt_hip_buffer_describe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
     lib.crt_hip_buffer_stats.restype = ctypes.c_int

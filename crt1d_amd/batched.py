@@ -331,6 +331,21 @@ def buffer_stats(device=None):
     return dict(zip(("chunks_created", "chunks_released", "probes", "probe_us", "free_chunks", "classes_seen"), [int(v) for v in a]))
 
 
+def trim_buffers(device=None):
+    """Hand the set allocator's pooled chunks of the current (or given) device back to the driver (``crt_hip_buffer_trim``).  The pool
+    keeps at most its retention cap anyway (8 GB by default, :func:`set_pool_retention`); call this before a large allocation through
+    another allocator (``torch.empty``, RCCL buffers) when every GB counts."""
+    lib = _lib.load()
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        _lib.check(lib.crt_hip_buffer_trim(), "crt_hip_buffer_trim")
+
+
+def set_pool_retention(nbytes):
+    """Cap on the memory the set allocator's per-device pools keep after buffers are freed (``crt_hip_buffer_set_retain``;
+    default 8 GB, or ``CRT1D_POOL_RETAIN_MB``).  Applied at once to the existing pools."""
+    _lib.check(_lib.load().crt_hip_buffer_set_retain(int(nbytes)), "crt_hip_buffer_set_retain")
+
+
 PLACED_MIN_BYTES = 1 << 30  # below this the whole output set lives in the 256 MB Infinity Cache / a few chunks: plain torch memory
 
 
@@ -348,7 +363,13 @@ def alloc_outputs(scheme, ncol, nz, nb, device, dtype=torch.float64, placed=Fals
             return dict(zip(shapes, device_buffers(list(shapes.values()), dtype, device)))
         except RuntimeError:
             pass  # placement is a performance feature: any device memory is correct
-    return {k: torch.empty(s, dtype=dtype, device=device) for k, s in shapes.items()}
+    try:
+        return {k: torch.empty(s, dtype=dtype, device=device) for k, s in shapes.items()}
+    except torch.OutOfMemoryError:
+        # what the set allocator's pool still holds is invisible to torch's caching allocator: release it and try once more
+        trim_buffers(device)
+        torch.cuda.empty_cache()
+        return {k: torch.empty(s, dtype=dtype, device=device) for k, s in shapes.items()}
 
 
 class Plan:

@@ -23,8 +23,17 @@
 //    space only (47-bit space; a 72 GB set can be allocated ~1800 times per process).
 //  * one handle can be mapped at two addresses at once; a chunk keeps the "home" mapping it was classified through and is
 //    mapped a second time into the array it serves.
-// Chunks of freed buffers go back to a per-device pool (still classified) and are reused; crt_hip_buffer_trim releases them.
+// Chunks of freed buffers go back to a per-device pool (still classified) and are reused -- up to a RETENTION CAP (default 8 GB per
+// device, CRT1D_POOL_RETAIN_MB): what a freed buffer brings beyond the cap goes straight back to the driver (most common class first),
+// so that dropping a plan with a 70 GB output set does not leave 70 GB where torch's caching allocator, an RCCL buffer or another
+// process cannot get at it.  crt_hip_buffer_trim releases the rest.
+// Exploration (allocating and classifying more chunks than the request needs, to find the other classes) is bounded: at most half of
+// the memory that would stay free after the request, at most 96 GB, and it is abandoned for good on a device that still shows ONE class
+// after 32 GB (another GPU model or partition mode: nothing to balance there).  Probes run on a private non-blocking stream, so busy
+// torch streams do not distort their timing; they synchronise the host, so a Plan must be constructed outside stream capture.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include <algorithm>
 #include <map>
@@ -72,6 +81,9 @@ struct Pool {
   int nref = 0;
   double single_ms = 0.0;  // the pattern into one chunk alone
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t stream = nullptr;  // private, non-blocking: the probes
+  bool one_class = false;        // exploration found a single class in 32 GB: never explore again on this device
+  long long explored = 0;        // chunks classified by exploration so far (statistics / the rule above)
   // statistics (crt_hip_buffer_stats)
   long long created = 0, released = 0, probes = 0;
   double probe_ms_total = 0.0;
@@ -134,17 +146,19 @@ bool new_chunk(Pool& p, int dev, Chunk& c) {
   return true;
 }
 
-// average time of the store pattern into one or two chunks (null stream; the caller holds g_mu)
+// average time of the store pattern into one or two chunks (the pool's private stream; the caller holds g_mu)
 double probe_ms(Pool& p, char* a, char* b) {
   if (!p.e0) {
     if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return -1.0;
+    if (hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess) p.stream = nullptr;  // (null stream as a last resort)
   }
   const int na = b ? 2 : 1, reps = 3;
-  hipLaunchKernelGGL(k_probe_cols, dim3(P_COLS), dim3(512), 0, 0, reinterpret_cast<double*>(a), reinterpret_cast<double*>(b ? b : a), na);
-  (void)hipEventRecord(p.e0, 0);
+  hipStream_t st = p.stream;
+  hipLaunchKernelGGL(k_probe_cols, dim3(P_COLS), dim3(512), 0, st, reinterpret_cast<double*>(a), reinterpret_cast<double*>(b ? b : a), na);
+  (void)hipEventRecord(p.e0, st);
   for (int i = 0; i < reps; ++i)
-    hipLaunchKernelGGL(k_probe_cols, dim3(P_COLS), dim3(512), 0, 0, reinterpret_cast<double*>(a), reinterpret_cast<double*>(b ? b : a), na);
-  (void)hipEventRecord(p.e1, 0);
+    hipLaunchKernelGGL(k_probe_cols, dim3(P_COLS), dim3(512), 0, st, reinterpret_cast<double*>(a), reinterpret_cast<double*>(b ? b : a), na);
+  (void)hipEventRecord(p.e1, st);
   if (hipEventSynchronize(p.e1) != hipSuccess) return -1.0;
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, p.e0, p.e1) != hipSuccess) return -1.0;
@@ -187,6 +201,37 @@ bool classify(Pool& p, Chunk& c) {
 }
 
 char cls_letter(int c) { return c < NCLS ? "XYZ"[c] : '?'; }
+
+long long g_retain = -1;  // chunks a pool may keep; -1 = not set yet (CRT1D_POOL_RETAIN_MB or 8 GB); guarded by g_mu
+size_t retain_chunks() {
+  if (g_retain < 0) {
+    const char* e = getenv("CRT1D_POOL_RETAIN_MB");
+    const long long mb = e ? atoll(e) : 8192;
+    g_retain = (mb < 0 ? 0 : mb) / 512;
+  }
+  return (size_t)g_retain;
+}
+
+// keep at most `keep` free chunks in the pool: release from the most common class first (the rare ones are what the next
+// request will be short of), ambiguous chunks before everything else
+void cap_pool(Pool& p, size_t keep) {
+  while (p.free_chunks.size() > keep) {
+    size_t cnt[NCLS + 1] = {0, 0, 0, 0};
+    for (auto& c : p.free_chunks) ++cnt[c.cls <= NCLS ? c.cls : NCLS];
+    int worst = NCLS;
+    if (cnt[NCLS] == 0) {
+      worst = 0;
+      for (int c = 1; c < NCLS; ++c)
+        if (cnt[c] > cnt[worst]) worst = c;
+    }
+    for (size_t k = p.free_chunks.size(); k-- > 0;)
+      if (p.free_chunks[k].cls == worst) {
+        release_chunk(p, p.free_chunks[k]);
+        p.free_chunks.erase(p.free_chunks.begin() + k);
+        break;
+      }
+  }
+}
 
 }  // namespace
 
@@ -232,11 +277,20 @@ int crt_hip_buffer_alloc_set(int32_t n, const size_t* bytes, void** ptrs) {
   size_t free0 = 0, tot0 = 0;
   if (hipMemGetInfo(&free0, &tot0) != hipSuccess) free0 = need * CHUNK + (22ull << 30);
   free0 += have.size() * CHUNK;  // what the pool already holds counts as available to this request
-  const size_t budget = std::min<size_t>(free0 > (6ull << 30) ? free0 - (6ull << 30) : 0, need * CHUNK + (96ull << 30));
+  const size_t hard = free0 > (6ull << 30) ? free0 - (6ull << 30) : 0;  // never take the last 6 GB of the device
+  // exploration: at most half of what would stay free after the request, at most 96 GB, nothing on a one-class device
+  const size_t spare = hard > need * CHUNK ? hard - need * CHUNK : 0;
+  const size_t extra = p.one_class ? 0 : std::min<size_t>(spare / 2, 96ull << 30);
+  const size_t budget = std::min(hard, need * CHUNK + extra);
+  constexpr long long ONE_CLASS_AFTER = 64;  // chunks (32 GB) classified with a single class seen
   bool oom = false;
-  while (!balanced()) {
-    if ((have.size() + 1) * CHUNK > budget) {
+  while (have.size() < need || !balanced()) {
+    if ((have.size() + 1) * CHUNK > (have.size() < need ? hard : budget)) {
       oom = have.size() < need;
+      break;
+    }
+    if (have.size() >= need && p.nref <= 1 && p.explored >= ONE_CLASS_AFTER) {
+      p.one_class = true;  // remembered: later requests take their chunks and go
       break;
     }
     Chunk c;
@@ -244,6 +298,7 @@ int crt_hip_buffer_alloc_set(int32_t n, const size_t* bytes, void** ptrs) {
       oom = have.size() < need;
       break;
     }
+    if (have.size() >= need) ++p.explored;
     if (classify(p, c)) have.push_back(c);
   }
   if (have.size() < need) {
@@ -293,7 +348,8 @@ int crt_hip_buffer_alloc_set(int32_t n, const size_t* bytes, void** ptrs) {
       const size_t cx = x.cls < NCLS ? avail[x.cls] : (size_t)-1, cy = y.cls < NCLS ? avail[y.cls] : (size_t)-1;
       return cx < cy;
     });
-    while (have.size() > 6) {
+    const size_t keep = std::max<size_t>(6, retain_chunks());  // spares survive so that the next request need not explore again
+    while (have.size() > keep) {
       release_chunk(p, have.back());
       have.pop_back();
     }
@@ -352,6 +408,7 @@ int crt_hip_buffer_free(void* ptr) {
   retire_range(ptr, b.size);
   Pool& p = g_pools[b.dev];
   for (auto& c : b.chunks) p.free_chunks.push_back(c);
+  cap_pool(p, retain_chunks());  // beyond the retention cap the memory goes back to the driver now
   return CRT_OK;
 }
 
@@ -363,6 +420,13 @@ int crt_hip_buffer_trim(void) {
   if (it == g_pools.end()) return CRT_OK;
   for (auto& c : it->second.free_chunks) release_chunk(it->second, c);
   it->second.free_chunks.clear();
+  return CRT_OK;
+}
+
+int crt_hip_buffer_set_retain(size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_retain = (long long)(bytes / CHUNK);
+  for (auto& kv : g_pools) cap_pool(kv.second, (size_t)g_retain);
   return CRT_OK;
 }
 

@@ -253,9 +253,14 @@ int crt_hip_lai_beta_f64(const double* h_c, const double* LAI, const double* h_m
  * virtual-memory API), classifies every new chunk with a ~1 ms probe, and interleaves the classes across the arrays so that a
  * kernel sweeping all n arrays in step always writes a balanced mix.  ptrs[a] receives a device pointer to at least bytes[a]
  * bytes (2 MB aligned).  Buffers belong to the current device; free each with crt_hip_buffer_free after all work that uses it
- * has completed (its chunks return to a per-device pool; crt_hip_buffer_trim hands the pool's memory back to the driver).
- * Synchronous (like hipMalloc); may run short probe kernels on the null stream.  No counterpart in the reference (NumPy owns
- * its arrays).  crt_hip_buffer_alloc = a set of one.
+ * has completed.  Its chunks return to a per-device pool that keeps at most a RETENTION CAP (8 GB by default; environment
+ * CRT1D_POOL_RETAIN_MB, or crt_hip_buffer_set_retain(bytes), which also applies the new cap at once): what exceeds the cap goes back
+ * to the driver inside crt_hip_buffer_free, so freeing a large set makes its memory available to every other allocator again;
+ * crt_hip_buffer_trim hands back the rest.  Looking for chunks of other classes ("exploration") transiently takes at most half of the
+ * memory that stays free beside the request (<= 96 GB), and is abandoned for good on a device that shows a single class.
+ * Synchronous (like hipMalloc): runs short probe kernels on a private stream and waits for them -- not capturable into a hipGraph,
+ * so allocate (and construct plans) outside stream capture.  No counterpart in the reference (NumPy owns its arrays).
+ * crt_hip_buffer_alloc = a set of one.
  * crt_hip_buffer_describe writes one letter per chunk of a buffer (X / Y / Z = class, ? = ambiguous) into buf;
  * crt_hip_buffer_stats fills {chunks created, chunks released, probes run, probe microseconds, free chunks, classes seen}.
  */
@@ -263,6 +268,7 @@ int crt_hip_buffer_alloc_set(int32_t n, const size_t* bytes, void** ptrs);
 int crt_hip_buffer_alloc(size_t bytes, void** ptr);
 int crt_hip_buffer_free(void* ptr);
 int crt_hip_buffer_trim(void);
+int crt_hip_buffer_set_retain(size_t bytes);
 int crt_hip_buffer_describe(const void* ptr, char* buf, size_t n);
 int crt_hip_buffer_stats(int64_t* out6);
 

@@ -461,10 +461,11 @@ def test_device_buffer_set_lifecycle():
         _lib.check(_lib.load().crt_hip_buffer_free(12345), "crt_hip_buffer_free")
 
 
-def test_buffer_pool_memory_counts_as_available():
-    """Regression (round 2): the chunks of a freed set stay in the per-device pool; a following request larger than what is FREE but
-    smaller than free + pool must succeed (the exploration budget counts the pool's memory), and a request that cannot be met hands
-    everything back instead of sitting on it (the caller falls back to torch.empty, which needs that memory)."""
+def test_buffer_pool_retention_cap_and_availability():
+    """The chunks of a freed set go back to the per-device pool only up to its retention cap (8 GB by default; ADVICE round 2: a dropped
+    plan must not leave tens of GB where no other allocator can reach them); the rest returns to the driver inside crt_hip_buffer_free.
+    A following request larger than what is FREE but smaller than free + pool must succeed (the budget counts the pool's memory), and a
+    request that cannot be met hands everything back instead of sitting on it (the caller falls back to torch.empty, which needs it)."""
     import gc
 
     import torch
@@ -482,6 +483,17 @@ def test_buffer_pool_memory_counts_as_available():
     n8 = lambda gb: (int(gb * (1 << 30)) // 8,)  # noqa: E731
     a = batched.device_buffers([n8(10)] * 3)       # 30 GB
     a[0][:16] = 1.0
+    held, _ = torch.cuda.mem_get_info()
+    del a
+    gc.collect()                                   # -> at most 16 chunks (8 GB) stay in the pool, >= 22 GB are free again
+    assert 1 <= batched.buffer_stats()["free_chunks"] <= 16
+    back, _ = torch.cuda.mem_get_info()
+    assert back - held >= (21 << 30), (held, back)
+    big = torch.empty(20 << 30, dtype=torch.uint8, device="cuda")  # ... and torch's allocator can have them
+    del big
+    torch.cuda.empty_cache()
+    batched.set_pool_retention(40 << 30)           # a larger cap for the second half of the test
+    a = batched.device_buffers([n8(10)] * 3)
     del a
     gc.collect()                                   # -> 60 chunks in the pool, ~34 GB free
     assert batched.buffer_stats()["free_chunks"] >= 60
@@ -493,220 +505,10 @@ def test_buffer_pool_memory_counts_as_available():
         batched.device_buffers([n8(20)] * 4)
     free_after, _ = torch.cuda.mem_get_info()
     assert free_after >= (64 - 44 - 8) << 30       # ... without keeping what it gathered
+    batched.set_pool_retention(8 << 30)            # back to the default: applied at once
     del b, ballast
     gc.collect()
-    lib.crt_hip_buffer_trim()
+    assert batched.buffer_stats()["free_chunks"] <= 16
+    batched.trim_buffers()
+    assert batched.buffer_stats()["free_chunks"] == 0
     torch.cuda.empty_cache()
-
-
-def test_common_tau_functions_vs_reference():
-    """Row a7 as public API: tau_b_fn, tau_df_fn ('quad' / '9sky'), K_df_fn of crt1d.solvers.common (golden g9_common.npz from the
-    reference).  '9sky' involves no quadrature: 1e-13; 'quad' is bounded by the reference's QUADPACK error (<= 2e-7 here)."""
-    from crt1d_amd import leaf_angle
-    from crt1d_amd.solvers import common
-
-    g = load_golden("g9_common")
-    lai = g["lai"]
-    gfs = {"spherical": leaf_angle.G_spherical, "horizontal": leaf_angle.G_horizontal, "vertical": leaf_angle.G_vertical,
-           "ellipsoidal_x2": lambda p: leaf_angle.G_ellipsoidal(p, 2.0),
-           "ellipsoidal_approx_x0.96": lambda p: leaf_angle.G_ellipsoidal_approx(p, 0.9632)}
-    for name, G in gfs.items():
-        K = lambda p, G=G: G(p) / np.cos(p)  # noqa: E731  (a plain lambda, as the reference's Model builds it)
-        np.testing.assert_allclose(common.tau_b_fn(K, 0.35, lai), g[f"{name}__tau_b"], rtol=1e-15)
-        np.testing.assert_allclose(common.tau_df_fn(K, lai, method="9sky"), g[f"{name}__tau_d_9sky"], rtol=1e-13, err_msg=name)
-        np.testing.assert_allclose(common.tau_df_fn(K, lai, method="quad"), g[f"{name}__tau_d_quad"], rtol=2e-7, err_msg=name)
-        np.testing.assert_allclose(common.tau_df_fn(K, lai), g[f"{name}__tau_d_quad"], rtol=2e-7)  # default method
-        s = common.tau_df_fn(K, 2.5)
-        assert isinstance(s, float) and s == pytest.approx(float(g[f"{name}__tau_d_quad_scalar"]), rel=2e-7)
-        assert common.K_df_fn(K, 4.0) == pytest.approx(float(g[f"{name}__K_d_quad"]), rel=2e-7)
-        assert common.K_df_fn(K, 4.0, method="9sky") == pytest.approx(float(g[f"{name}__K_d_9sky"]), rel=1e-13)
-    with pytest.raises(ValueError):
-        common.tau_df_fn(lambda p: 0.5 / np.cos(p), lai, method="simpson")
-
-
-@pytest.mark.parametrize("shape", [(23, 300, 60), (130, 64, 13), (5, 600, 33), (4, 128, 150), (3, 300, 250), (6, 300, 3), (5, 300, 2), (7, 96, 101),
-                                   (9, 38, 100), (11, 16, 30), (6, 36, 130), (8, 62, 61),
-                                   (9, 107, 60), (7, 107, 61), (5, 299, 100), (4, 17, 33), (3, 65, 150), (5, 129, 2), (2, 601, 40), (6, 63, 101)])
-@pytest.mark.parametrize("uniform", [True, False])
-def test_zq_pa_fused_interpolation_equals_two_kernel_path(shape, uniform):
-    """zq_pa in one kernel (the store waves interpolate from the computational grid to the caller's levels; no workspace scratch) must be
-    BITWISE the two-kernel path (grid solve into scratch + k_zqpa_interp; crt_options.tune[10] = 1 selects it): same expressions, and the
-    rounds must hand every output level exactly the computational rows it needs (nz below, at and above the 100-layer grid)."""
-    import torch
-
-    from crt1d_amd import batched, synth
-
-    d = synth.make_columns(*shape, seed=5, uniform_dlai=uniform)
-    cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
-    ref = batched.Plan("zq_pa", cols, bands, tune={10: 1})
-    ref()
-    torch.cuda.synchronize()
-    assert "two-kernel" in ref.last_kernel()
-    for nsw in (0, 1, 4):
-        p = batched.Plan("zq_pa", cols, bands, tune={11: nsw})
-        for v in p.out.values():
-            v.fill_(float("nan"))
-        p()
-        torch.cuda.synchronize()
-        assert "k_zqpa_pipe" in p.last_kernel() and ("flat" in p.last_kernel()) == bool(shape[1] % 2)
-        for k in ref.out:
-            assert torch.equal(p.out[k], ref.out[k]), (k, nsw)
-
-
-@pytest.mark.parametrize("scheme", ["2s", "n79", "zq"])
-def test_g6_epilogue_kernels_vs_reference_golden(scheme):
-    """Rows a11 / a12 pinned on the reference itself: crt_hip_absorb_f64 and crt_hip_absorb_bandsum_f64 fed with the REFERENCE's
-    profiles (g1) against the reference's own `_calc_absorption` (model.py:573-647) outputs and the band sums formed with its
-    `_x_frac_in_bounds` weights (fixture g6, oracle/gen_golden.py)."""
-    import torch
-
-    from crt1d_amd import batched, spectra
-
-    g1, g6 = load_golden("g1_default"), load_golden("g6_absorption")
-    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()  # noqa: E731
-    cols = batched.Columns(t([float(g1["psi"])]), t(g1["lai"][None]), torch.tensor([4], dtype=torch.int32).cuda(), t([float(g1["x"])]))
-    bands = batched.Bands(t(g1["I_dr0_all"]), t(g1["I_df0_all"]), t(g1["leaf_r"]), t(g1["leaf_t"]), t(g1["soil_r"]))
-    sol = {k: t(g1[f"{scheme}__{k}"][None]) for k in ("I_dr", "I_df_d", "I_df_u")}
-    per = batched.absorb(cols, bands, sol)
-    scale = np.abs(g6[f"{scheme}__aI"]).max()
-    for k in batched.ABSORPTION_KEYS + ("laim", "f_slm"):
-        ref = g6[f"{scheme}__{k}"]
-        assert np.max(np.abs(per[k].cpu().numpy()[0] - ref)) <= 1e-13 * max(scale, np.abs(ref).max()), k
-    # weights: the host-side restatement of _x_frac_in_bounds is bit-exact against the reference's
-    names = [str(n) for n in g6["band_names"]]
-    W = np.stack([spectra.x_frac_in_bounds(g6["wle"], tuple(g6["band_bounds"][i])) for i in range(len(names))])
-    np.testing.assert_array_equal(W, g6["w_default"])
-    res = batched.absorb_bandsum(cols, bands, sol, t(W))
-    for k in ("aI", "aI_sl", "aI_sh"):
-        ref = g6[f"{scheme}__{k}__bandsum"]  # (ngroup, nz-1)
-        got = res[k].cpu().numpy()[0].T
-        assert np.max(np.abs(got - ref)) <= 1e-12 * np.abs(ref).max(), k
-
-
-def test_g6_epilogue_ragged_columns():
-    import torch
-
-    from crt1d_amd import batched
-
-    g4, g6 = load_golden("g4_ragged"), load_golden("g6_absorption")
-    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()  # noqa: E731
-    cols = batched.Columns(t(g4["psi"]), t(g4["lai"]), t(g4["g_kind"].astype(np.int32)), t(g4["g_param"]))
-    bands = batched.Bands(t(g4["I_dr0"]), t(g4["I_df0"]), t(g4["leaf_r"]), t(g4["leaf_t"]), t(g4["soil_r"]))
-    sol = {k: t(g4[f"2s__{k}"]) for k in ("I_dr", "I_df_d", "I_df_u")}
-    per = batched.absorb(cols, bands, sol)
-    for k in batched.ABSORPTION_KEYS + ("laim", "f_slm"):
-        ref = g6[f"ragged2s__{k}"]
-        assert np.max(np.abs(per[k].cpu().numpy() - ref)) <= 1e-13 * max(1.0, np.abs(ref).max()), k
-    res = batched.absorb_bandsum(cols, bands, sol, t(g6["w_synth"]))
-    for k in ("aI", "aI_sl", "aI_sh"):
-        ref = np.einsum("czb,gb->czg", g6[f"ragged2s__{k}"], g6["w_synth"])
-        assert np.max(np.abs(res[k].cpu().numpy() - ref)) <= 1e-12 * np.abs(ref).max(), k
-
-
-def test_argument_checks_at_the_python_boundary():
-    """The C ABI takes bare pointers; everything a kernel assumes about caller-supplied arrays is checked before the call
-    (round-1 advisor findings): dtype / shape / device of outputs, profiles, workspace, band_w; missing G tables."""
-    import torch
-
-    from crt1d_amd import batched, spectra, synth
-
-    d = synth.make_columns(6, 40, 12, seed=1)
-    cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
-    w = torch.as_tensor(spectra.band_weights(d["wle"])).cuda()
-    # f32 solve followed by the fp64 epilogue: float profiles read as double would run past the allocation
-    b32 = batched.Bands(*[t.float() for t in (bands.I_dr0, bands.I_df0, bands.leaf_r, bands.leaf_t, bands.soil_r)])
-    s32 = batched.solve("2s", cols, b32)
-    with pytest.raises(TypeError):
-        batched.absorb_bandsum(cols, b32, s32, w)
-    with pytest.raises(TypeError):
-        batched.absorb(cols, bands, s32)  # f64 spectra but f32 profiles
-    sol = batched.solve("n79", cols, bands)
-    with pytest.raises(ValueError):
-        batched.absorb_bandsum(cols, bands, {k: v[:, :-1] for k, v in sol.items()}, w)  # wrong shape (and non-contiguous)
-    with pytest.raises(ValueError):
-        batched.absorb_bandsum(cols, bands, sol, w[:, :-1].contiguous())  # band_w of the wrong width
-    # caller-supplied outputs: n79's mid-level arrays are (ncol, nz-1, nb) -- an (ncol, nz, nb) array in their place is an error
-    out = {k: torch.empty((6, 12, 40), dtype=torch.float64, device="cuda") for k in batched.OUT_KEYS["n79"]}
-    with pytest.raises(ValueError):
-        batched.Plan("n79", cols, bands, out=out)
-    out["aI_lsl"] = torch.empty((6, 11, 40), dtype=torch.float64, device="cuda")
-    out["aI_lsh"] = torch.empty((6, 11, 40), dtype=torch.float64, device="cuda")
-    p = batched.Plan("n79", cols, bands, out=out)
-    p()
-    torch.cuda.synchronize()
-    for k in sol:
-        assert torch.equal(out[k], sol[k]), k
-    with pytest.raises(TypeError):
-        batched.Plan("n79", cols, bands, out={k: v.float() for k, v in out.items()})
-    with pytest.raises(ValueError):
-        batched.Plan("n79", cols, bands, workspace=torch.empty(16, dtype=torch.uint8, device="cuda"))
-    with pytest.raises(ValueError):
-        batched.Plan("n79", cols, bands, workspace=torch.empty(1 << 20, dtype=torch.uint8))  # host memory
-    with pytest.raises(ValueError):
-        batched.IntegratedPlan("n79", cols, bands, w, workspace=torch.empty(16, dtype=torch.uint8, device="cuda"))
-    # columns that ask for a sampled G table without bringing one
-    d6 = dict(d, g_kind=np.full(6, 6, dtype=np.int32))
-    c6 = batched.Columns.from_host(d6)
-    with pytest.raises(ValueError):
-        batched.Plan("2s", c6, bands)
-    with pytest.raises(ValueError):
-        batched.absorb_bandsum(c6, bands, batched.solve("2s", cols, bands), w)
-
-
-@pytest.mark.parametrize("scheme,shape", [("2s", (200, 300, 60)), ("zq", (60, 300, 100)), ("n79", (40, 107, 60))])
-def test_plan_is_capturable_into_a_hip_graph(scheme, shape):
-    """After the first call on a device (which uploads the quadrature tables) a Plan's launches are stream-only: K0 + solve can be
-    captured into a hipGraph (torch.cuda.CUDAGraph) and replayed, bitwise the same outputs, also after the inputs change in place."""
-    import torch
-
-    from crt1d_amd import batched, synth
-
-    d = synth.make_columns(*shape, seed=3)
-    cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
-    plan = batched.Plan(scheme, cols, bands, placement="none")
-    plan()
-    torch.cuda.synchronize()
-    ref = {k: v.clone() for k, v in plan.out.items()}
-    s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        plan()
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=s):
-        plan()
-    for v in plan.out.values():
-        v.zero_()
-    g.replay()
-    torch.cuda.synchronize()
-    for k in ref:
-        assert torch.equal(plan.out[k], ref[k]), k
-    bands.I_df0.mul_(2.0)  # same buffers, new spectra: the replay reads them through the captured pointers
-    g.replay()
-    torch.cuda.synchronize()
-    fresh = batched.Plan(scheme, cols, bands, placement="none")()
-    torch.cuda.synchronize()
-    for k in ref:
-        assert torch.equal(plan.out[k], fresh[k]), k
-
-
-def test_store_set_probe():
-    """crt_hip_probe_store_set_f64 (the flush pattern of the solve kernels on a set of arrays): fills every array with the value, rejects bad
-    arguments."""
-    import ctypes
-
-    import torch
-
-    from crt1d_amd import _lib
-
-    lib = _lib.load()
-    ncol, col, run = 37, 60 * 38, 8 * 38
-    arrs = [torch.zeros(ncol * col, dtype=torch.float64, device="cuda") for _ in range(3)]
-    ptrs = (ctypes.c_void_p * 3)(*[a.data_ptr() for a in arrs])
-    st = torch.cuda.current_stream().cuda_stream
-    assert lib.crt_hip_probe_store_set_f64(ptrs, 3, ncol, col, run, 2.5, st) == 0
-    torch.cuda.synchronize()
-    for a in arrs:
-        assert bool((a == 2.5).all())
-    assert lib.crt_hip_probe_store_set_f64(ptrs, 0, ncol, col, run, 2.5, st) != 0
-    assert lib.crt_hip_probe_store_set_f64(ptrs, 3, ncol, col + 1, run, 2.5, st) != 0
-    assert lib.crt_hip_probe_store_set_f64(ptrs, 3, ncol, col, 3, 2.5, st) != 0
