@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrt1d_hip.so")
+# CRT1D_HIP_LIB: measurement aid only -- an alternative build of the SAME library (tools/build_variant.sh) for in-round A/B runs
+LIB_PATH = os.environ.get("CRT1D_HIP_LIB") or os.path.join(_HERE, "libcrt1d_hip.so")
 
 # enum crt_scheme
 SCHEME_IDS = {"2s": 0, "4s": 1, "n79": 2, "zq": 3, "bl": 4, "g77": 5, "bf": 6, "zq_pa": 7}
@@ -109,6 +110,7 @@ EXPORTS = [
     "crt_hip_probe_fill_f64",
     "crt_hip_probe_copy_f64",
     "crt_hip_probe_store_set_f64",
+    "crt_hip_probe_math_f64",
 ]
 
 _lib = None
@@ -199,6 +201,8 @@ def load():
     lib.crt_hip_probe_fill_f64.argtypes = [_vp, ctypes.c_size_t, ctypes.c_double, _vp]
     lib.crt_hip_probe_copy_f64.restype = ctypes.c_int
     lib.crt_hip_probe_copy_f64.argtypes = [_vp, _vp, ctypes.c_size_t, _vp]
+    lib.crt_hip_probe_math_f64.restype = ctypes.c_int
+    lib.crt_hip_probe_math_f64.argtypes = [_vp, ctypes.c_size_t, _vp, _vp, _vp, _vp]
     lib.crt_hip_probe_store_set_f64.restype = ctypes.c_int
     lib.crt_hip_probe_store_set_f64.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, _vp]
     if lib.crt_hip_abi_version() != 2:

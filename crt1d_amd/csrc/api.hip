@@ -768,6 +768,16 @@ __global__ __launch_bounds__(256) void k_absorb_tile(AbsArgs a, int T) {
 
 // ------------------------------------------------------------------------------------------
 // bandwidth probes: plain 16-B-per-lane streaming fill / copy, grid-stride
+__global__ __launch_bounds__(256) void k_probe_math(const double* x, size_t n, double* e, double* sn, double* cs) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  e[i] = fexp(x[i]);
+  double s_, c_;
+  fast_sincos(x[i], s_, c_);
+  sn[i] = s_;
+  cs[i] = c_;
+}
+
 __global__ __launch_bounds__(256) void k_fill(d2* dst, size_t n2, double v) {
   d2 t;
   t.x = v;
@@ -1177,6 +1187,14 @@ int crt_hip_probe_store_set_f64(double* const* arrays, int32_t narrays, int64_t 
   a.col = col_doubles;
   a.run = run_doubles;
   hipLaunchKernelGGL(k_store_set, dim3((unsigned)ncol), dim3(192), 0, static_cast<hipStream_t>(stream), a, value);
+  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+}
+
+// the device math the kernels use instead of ocml's exp / sincos (crt_internal.hpp: fexp, fast_sincos), exposed so that a test can
+// bound their error in ulps over the arguments the schemes produce
+int crt_hip_probe_math_f64(const double* x, size_t n, double* e, double* sn, double* cs, crt_stream_t stream) {
+  if (!x || !e || !sn || !cs || n == 0 || n > 0x7fffffffull * 256) return CRT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_probe_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, e, sn, cs);
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 

@@ -119,13 +119,13 @@ static_assert(K0_BLOCK == 8 * BL_CHUNK && CRT_NQ_TAU % 8 == 0, "bl chunk reducti
 
 __device__ inline double tau_d_quad(const double* kq, double L) {
   double s = 0.0;
-  for (int q = 0; q < NQT; ++q) s += qc.w2sc[q] * exp(-kq[q] * L);
+  for (int q = 0; q < NQT; ++q) s += qc.w2sc[q] * fexp(-kq[q] * L);
   return s;
 }
 
 __device__ inline double tau_d_9sky(const double* k9, double L) {
   double s = 0.0;
-  for (int i = 0; i < CRT_NQ_9SKY; ++i) s += exp(-k9[i] * L) * qc.sc9[i];
+  for (int i = 0; i < CRT_NQ_9SKY; ++i) s += fexp(-k9[i] * L) * qc.sc9[i];
   return s * (2.0 * 0.17453292519943295);  // * 2 radians(10), common.py:51
 }
 
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
       rec[S_GINT2] = g2;
       rec[S_DLM] = dlm;
       rec[S_TAUI] = 0.0;
-      rec[S_TPSI] = a.scheme == CRT_SCHEME_ZQ ? exp(-Kb * dlm) : 0.0;  // _solve_zq.py:52
+      rec[S_TPSI] = a.scheme == CRT_SCHEME_ZQ ? fexp(-Kb * dlm) : 0.0;  // _solve_zq.py:52
       double cos2 = 0.0;
       if (a.scheme == CRT_SCHEME_2S) {
         const double cm = cos(a.mla[c] * (M_PI / 180.0));
@@ -242,13 +242,13 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
     // computational grid of M equal layers (_solve_zq_pa.py:94-100): tau_d(LAI/M) (:176), exp(-K_b LAI/M) (:174)
     const int M = zqpa_M(nz);
     const double Lm = lai[0] / M;
-    for (int q = tid; q < NQT; q += K0_BLOCK) pmb[q] = qc.w2sc[q] * exp(-kq[q] * Lm);
+    for (int q = tid; q < NQT; q += K0_BLOCK) pmb[q] = qc.w2sc[q] * fexp(-kq[q] * Lm);
     __syncthreads();
     if (wave == 0) {
       const double t = wave_sum64(pmb[lane] + (lane < NQT - 64 ? pmb[64 + lane] : 0.0));
       if (lane == 0) {
         rec[S_TAUI] = t;
-        rec[S_TPSI] = exp(-Kb * Lm);
+        rec[S_TPSI] = fexp(-Kb * Lm);
         // xi[i] = cumulative LAI of computational interface i from the top, built by repeated addition as np.cumsum
         // does (_solve_zq_pa.py:159): xi[0] = 0, xi[i] = xi[i-1] + Lm
         double sacc = 0.0;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   if (a.scheme == CRT_SCHEME_ZQ) {
     // tau_i = tau_d(dlai_mean), always 'quad' (_solve_zq.py:51): one node per thread, then the same tree reduction
     const double dlm = sh_dlm;
-    for (int q = tid; q < NQT; q += K0_BLOCK) pmb[q] = qc.w2sc[q] * exp(-kq[q] * dlm);
+    for (int q = tid; q < NQT; q += K0_BLOCK) pmb[q] = qc.w2sc[q] * fexp(-kq[q] * dlm);
     __syncthreads();
     if (wave == 0) {
       const double t = wave_sum64(pmb[lane] + (lane < NQT - 64 ? pmb[64 + lane] : 0.0));
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
     if (a.tau_d_method == CRT_TAU_D_9SKY) {
       if (tid == 0) sh_tdu = tau_d_9sky(k9, dl);
     } else {
-      for (int q = tid; q < NQT; q += K0_BLOCK) pmb[q] = qc.w2sc[q] * exp(-kq[q] * dl);
+      for (int q = tid; q < NQT; q += K0_BLOCK) pmb[q] = qc.w2sc[q] * fexp(-kq[q] * dl);
       __syncthreads();
       if (wave == 0) {
         const double t = wave_sum64(pmb[lane] + (lane < NQT - 64 ? pmb[64 + lane] : 0.0));
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   if (blu) {
     const double dl = sh_dl;
     const bool on = tid < NQT;
-    const double E = on ? exp(-kq[on ? tid : 0] * dl) : 0.0;
+    const double E = on ? fexp(-kq[on ? tid : 0] * dl) : 0.0;
     const double w = on ? qc.w2sc[tid] : 0.0;
     double P = 1.0;  // level nz-1: L = 0
     for (int jtop = nz - 1; jtop >= 0; jtop -= BL_CHUNK) {  // levels jtop, jtop-1, ... (chunk position jj <-> level jtop - jj)
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   double* v = rec + REC_HDR;
   for (int j = tid; j < nz; j += K0_BLOCK) {
     const double L = lai[j];
-    const double ekl = exp(-Kb * L);
+    const double ekl = fexp(-Kb * L);
     switch (a.scheme) {
       case CRT_SCHEME_ZQ:
         v[j] = ekl;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
         const int M = zqpa_M(nz);
         auto xi = [&](int i) { return xis[i]; };
         // beam fraction seen by computational layer li = j+1 (:164-168): f_sl[li] = exp(-K_b xi[M+1-li])
-        v[j] = (j < M) ? exp(-Kb * xi(M - j)) : 0.0;
+        v[j] = (j < M) ? fexp(-Kb * xi(M - j)) : 0.0;
         v[nz + j] = ekl;
         // linear interpolation of the interface fluxes back to lai[j] (:357-362, np.interp semantics)
         int lo = 0;
@@ -366,13 +366,13 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
           const double Ln = lai[j + 1];
           const double dl = L - Ln;                                             // :40
           if (n79u) {
-            tb = exp(-Kb * sh_dl);
+            tb = fexp(-Kb * sh_dl);
             td = sh_tdu;
           } else {
-            tb = exp(-Kb * dl);                                                 // :45
+            tb = fexp(-Kb * dl);                                                 // :45
             td = (a.tau_d_method == CRT_TAU_D_9SKY) ? tau_d_9sky(k9, dl) : tau_d_quad(kq, dl);  // :53
           }
-          fs = exp(-Kb * ((L + Ln) / 2));                                       // :57-58
+          fs = fexp(-Kb * ((L + Ln) / 2));                                       // :57-58
           isl = 1.0 / (fs * dl);                                                // :154
           ish = 1.0 / ((1.0 - fs) * dl);                                        // :155
         }

@@ -223,6 +223,77 @@ __device__ inline double fast_rcp(double x) {
   return r;
 }
 
+// ------------------------------------------------------------------------------------------
+// Polynomial steps with the coefficient in a SCALAR register.  hipcc (ROCm 7.2) turns a Horner step fma(acc, r, C) whose constant it keeps
+// in a VGPR into v_mov_b64 tmp, C + v_fmac_f64 tmp, acc, r -- two issue slots per step (ISA of k_pipe<4s>, round 3: ocml's exp was 35
+// VALU instructions, 11 of them such copies).  v_fma_f64 takes one SGPR pair as a source, so the step is ONE instruction when the
+// constant is pinned to scalar registers; the asm is not volatile, the compiler still schedules and interleaves it freely.
+__device__ __forceinline__ double fma_vvs(double a, double b, double c_uniform) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+  return d;
+}
+__device__ __forceinline__ double fma_vsv(double a, double c_uniform, double b) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(c_uniform), "v"(b));
+  return d;
+}
+__device__ __forceinline__ double mul_vs(double a, double c_uniform) {
+  double d;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(c_uniform));
+  return d;
+}
+
+// e^x in 18 VALU instructions, <= 1 ulp: k = rint(x log2 e), r = x - k ln2 (two-term Cody-Waite, exact first product for |k| < 2^20),
+// e^r = 1 + r + r^2 q(r) with q the degree-9 interpolant of (e^r - 1 - r) / r^2 at the Chebyshev nodes of [-ln2/2, ln2/2] (coefficients
+// computed for this file with mpmath at 60 digits and rounded to double: 1.6e-17 relative in exact arithmetic), scaled by v_ldexp_f64 --
+// which underflows to 0 and overflows to inf by itself, so no range checks.  NaN in, NaN out.
+__device__ __forceinline__ double fexp(double x) {
+  const double k = __builtin_rint(mul_vs(x, 1.44269504088896338700e+00));
+  double r = fma_vsv(k, -6.93147180369123816490e-01, x);
+  r = fma_vsv(k, -1.90821492927058770002e-10, r);
+  double q = fma_vvs(r, 0x1.af389ecfc4b9cp-26, 0x1.28917c89a43a7p-22);
+  q = fma_vvs(q, r, 0x1.71de0db2f6b19p-19);
+  q = fma_vvs(q, r, 0x1.a019b9149a41cp-16);
+  q = fma_vvs(q, r, 0x1.a01a01a7c2efep-13);
+  q = fma_vvs(q, r, 0x1.6c16c17889ef1p-10);
+  q = fma_vvs(q, r, 0x1.11111111109b5p-7);
+  q = fma_vvs(q, r, 0x1.5555555553d68p-5);
+  q = fma_vvs(q, r, 0x1.5555555555556p-3);
+  q = fma_vvs(q, r, 0x1.0000000000001p-1);
+  q = __builtin_fma(q, r, 1.0);
+  q = __builtin_fma(q, r, 1.0);
+  return __builtin_ldexp(q, (int)k);
+}
+
+// sin and cos of a moderate argument (|th| < ~1e6) in ~35 instructions: two-term Cody-Waite reduction by pi/2 (the first product is
+// exact in the FMA for |th| < 2^20, the reduced argument is good to ~1.2e-16 absolute) and the minimax polynomials of fdlibm's
+// __kernel_sin / __kernel_cos on [-pi/4, pi/4].  Absolute error <= ~2e-16: the oscillatory modes of the four-stream scheme need
+// nothing better (ocml's sincos carries a Payne-Hanek path and double-double reduction: ~200 instructions).
+__device__ inline void fast_sincos(double th, double& sn, double& cs) {
+  const double k = __builtin_rint(mul_vs(th, 0.63661977236758134308));
+  double r = fma_vsv(k, -1.57079632679489655800e+00, th);
+  r = fma_vsv(k, -6.12323399573676603587e-17, r);
+  const double z = r * r;
+  double ps = fma_vvs(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma_vvs(z, ps, 2.75573137070700676789e-06);
+  ps = fma_vvs(z, ps, -1.98412698298579493134e-04);
+  ps = fma_vvs(z, ps, 8.33333333332248946124e-03);
+  ps = fma_vvs(z, ps, -1.66666666666666324348e-01);
+  const double sr = __builtin_fma(z * r, ps, r);
+  double pc = fma_vvs(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma_vvs(z, pc, -2.75573143513906633035e-07);
+  pc = fma_vvs(z, pc, 2.48015872894767294178e-05);
+  pc = fma_vvs(z, pc, -1.38888888888741095749e-03);
+  pc = fma_vvs(z, pc, 4.16666666666666019037e-02);
+  const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+  const int n = (int)k;
+  const bool swap = (n & 1) != 0;
+  const double ss = swap ? cr : sr, cc = swap ? sr : cr;
+  sn = (n & 2) ? -ss : ss;
+  cs = ((n + 1) & 2) ? -cc : cc;
+}
+
 // Levels at which the per-level exponentials are re-evaluated exactly when a column has uniform dlai; in between
 // they advance by one multiplication (e^{-h(L - dl)} = e^{-hL} e^{h dl}).  At most 7 products since the last exact
 // value -> <= 8 ulp; the rule depends on j only, so every kernel variant produces the same bits.

@@ -10,17 +10,20 @@
 // pattern decides the speed.  Measured on MI355X (tools/store_bw*.hip, profiles/r01_store_patterns.md):
 // lanes storing their own band directly write, per level, a 512-B/1-KiB run whose start is only
 // 8-B aligned whenever a row of nb doubles is not a multiple of 128 B (nb = 300: 2400 B) --
-// 3.0-3.9 TB/s; the same bytes written as 128-B-aligned contiguous chunks reach 5.5 TB/s
-// (the L2 does not merge partial lines, not even between waves of one CU).  Hence two kernels:
+// 3.0-3.9 TB/s; the same bytes written as 128-B-aligned contiguous chunks reach 5.5-7 TB/s
+// (the L2 does not merge partial lines, not even between waves of one CU).  Three kernels share the scheme objects
+// (and therefore produce identical bits):
 //
-//  k_tile   (default, nb >= 64): a workgroup owns CB whole columns.  Because the output is
-//           [ncol][nz][nb] with bands contiguous, T consecutive levels of one column form ONE
-//           contiguous run of T*nb doubles.  The lanes write their values into an LDS tile laid out
-//           exactly like that run; after T levels the workgroup flushes the run with 16-B-per-lane
-//           stores at consecutive addresses, so every wave store covers 8 whole 128-B lines.
-//           T = 16/gcd(nb,16) (times a small factor) makes every run start on a line boundary.
-//  k_direct (small nb, or tile does not fit in LDS): the original lane-stores-its-band kernel.
+//  k_pipe   (default, 4 <= nb <= 1024): ONE column per workgroup with the roles separated -- compute waves (one lane per
+//           band) fill a T-level LDS tile laid out exactly like the output run ([ncol][nz][nb] with bands contiguous:
+//           T consecutive levels of a column are ONE contiguous run of T*nb elements) while 1-3 STORE WAVES stream the
+//           previous tile out with 16-B-per-lane non-temporal stores (whole 128-B lines; double-buffered, one LDS-only
+//           barrier per tile).  Odd nb: the generic flush carries the part-line across tiles (whole lines only).
+//  k_tile   (tiles too large for two buffers -- g77 / bf at 300 bands -- or several narrow columns per workgroup): the same
+//           tile, all waves alternate between the level arithmetic and the flush.
+//  k_direct (nb < 4, or no tile fits in LDS): lanes store their own band per level.
 #include <algorithm>
+#include <type_traits>
 
 #include "crt_internal.hpp"
 
@@ -32,6 +35,18 @@ constexpr double PI = 3.14159265358979323846;
 struct BandIn {
   double I_dr0, I_df0, r, t, s;
 };
+
+// How a scheme's level() treats its per-level exponentials.  MODE 0: the column has ragged dlai -- evaluate them at every level;
+// MODE 1: uniform dlai -- advance by one multiplication per level, exact every 8th (exact_level); MODE 2: decide per lane from the K0
+// flag (kernels that mix columns in a workgroup).  k_pipe owns one column per workgroup and takes the decision ONCE, outside its level
+// loop: no per-level branch, no recurrence state carried through the ragged loop, and the exponentials of a level interleave freely.
+// Same arithmetic in every mode -> same bits.
+template <int MODE>
+__device__ __forceinline__ bool exact_here(bool unif, int j) {
+  if constexpr (MODE == 0) return true;
+  if constexpr (MODE == 1) return exact_level(j);
+  return !unif || exact_level(j);
+}
 
 template <typename TIO>
 __device__ inline BandIn load_band(const SolveArgs& a, int c, int b, bool need_soil) {
@@ -75,8 +90,8 @@ struct Sch2s {
     const double u1 = b - c / rs;                                      // :87
     const double u2 = b - c * rs;
     const double u3 = f + c * rs;
-    const double S1 = exp(-h * LT);
-    const double S2 = exp(-K * LT);
+    const double S1 = fexp(-h * LT);
+    const double S2 = fexp(-K * LT);
     const double mh = mb * h;
     const double p1 = b + mh, p2 = b - mh, p3 = b + mbK, p4 = b - mbK;
     const double iS1 = 1.0 / S1;
@@ -107,28 +122,30 @@ struct Sch2s {
     Bd = in.I_dr0 * h5 + in.I_df0 * h9;
     Cd = in.I_dr0 * h6 + in.I_df0 * h10;
     unif = rec[S_UNIF] != 0.0;
-    qp = exp(h * rec[S_DL]);  // lai decreases with j: e^{-hL} grows by e^{+h dl} per level
+    qp = fexp(h * rec[S_DL]);  // lai decreases with j: e^{-hL} grows by e^{+h dl} per level
     qm = fast_rcp(qp);
     em = ep = 1.0;
   }
 
   // levels must be visited in ascending order (both kernels sweep j = 0 .. nz-1)
+  template <int MODE = 2>
   __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) {
     const double L = rec[REC_HDR + j], eK = rec[REC_HDR + nz + j];
-    if (!unif || exact_level(j)) {
-      em = exp(-h * L);
+    if (exact_here<MODE>(unif, j)) {
+      em = fexp(-h * L);
       ep = fast_rcp(em);
     } else {
       em *= qp;
       ep *= qm;
     }
-    const double up = Au * eK + Bu * em + Cu * ep;
-    const double dn = Ad * eK + Bd * em + Cd * ep;
+    // (explicit FMAs: the build runs with -ffp-contract=off so that no kernel variant contracts differently from another)
+    const double up = __builtin_fma(Au, eK, __builtin_fma(Bu, em, Cu * ep));
+    const double dn = __builtin_fma(Ad, eK, __builtin_fma(Bd, em, Cd * ep));
     const double idr = I0 * eK;                    // :150
     o[0] = idr;
     o[1] = dn;
     o[2] = up;
-    o[3] = idr * invmu + 2 * up + 2 * dn;          // :156
+    o[3] = __builtin_fma(idr, invmu, 2 * (up + dn));  // :156
   }
 };
 
@@ -148,19 +165,20 @@ struct SchBl {
     I_df0 = in.I_df0;
     invmu = rec[S_INVMU];
     unif = rec[S_UNIF] != 0.0;
-    qg = exp(Kg * rec[S_DL]);
+    qg = fexp(Kg * rec[S_DL]);
     tg = 1.0;
   }
+  template <int MODE = 2>
   __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) {
     const double L = rec[REC_HDR + j], tb = rec[REC_HDR + nz + j], td = rec[REC_HDR + 2 * nz + j];
-    if (!unif || exact_level(j)) tg = exp(-Kg * L);               // :65
+    if (exact_here<MODE>(unif, j)) tg = fexp(-Kg * L);             // :65
     else tg *= qg;
     const double idr = I_dr0 * tb;                                // :69
     const double dn = I_df0 * td + 0.5 * (I_dr0 * (tg - tb));     // :70,74,79
     o[0] = idr;
     o[1] = dn;
     o[2] = 0.0;                                                   // :87
-    o[3] = idr * invmu + 2 * dn;                                  // :90
+    o[3] = __builtin_fma(idr, invmu, 2 * dn);                     // :90
   }
 };
 
@@ -176,6 +194,13 @@ struct SchG77 {
   double kb, invmu, LT, kp, kd, omr, cdf, csr, ct, gnd, I_dr0, I_df0, r, t;
   double ed, ex, er;      // e^{-kd L}, second scattered-light exponential (see level()), e^{-kd (LT - L)}
   double qd, qx, qr;      // their per-level factors for uniform dlai
+  // One exponential per level instead of three (bf) / two instead of three (g77): with m = LT / 2 and u = e^{-kd (L - m)},
+  //   e^{-kd L} = u cm,   e^{-kd (LT - L)} = cm / u,   bf: e^{kd L - (kb + kd) LT} = cx / u,      cm = e^{-kd m}, cx = e^{-(kb + kd/2) LT}.
+  // u is centred on the middle of the canopy, so 1/u cannot overflow unless kd LT / 2 > 700 (LAI > 1750: nothing the reference's own
+  // exponentials survive either), and the products underflow to zero exactly where the true values do -- no branch, no second code path
+  // (a guarded "evaluate each exponential by itself" path next to this one cost k_tile<g77> 32 registers and a quarter of its speed).
+  double hm, cm, cx;      // kd LT / 2, e^{-kd LT / 2}, bf: e^{-(kb + kd/2) LT}
+  double ikm, ikp;        // bf: 1/(kd - kb), 1/(kd + kb)
   bool unif;
 
   __device__ inline void init(const double* rec, const BandIn& in, const SolveArgs& a) {
@@ -197,28 +222,36 @@ struct SchG77 {
     csr = kd / sqrt(1 - in.r);
     ct = kd / sqrt(1 - in.t);
     // ground-level terms for the soil-reflected stream (g77:95, bf:112)
-    const double ed0 = exp(-kd * LT);
+    const double ed0 = fexp(-kd * LT);
+    hm = 0.5 * (kd * LT);
+    cm = fexp(-hm);
+    cx = BF ? fexp(-(kb + 0.5 * kd) * LT) : 0.0;
+    ikm = BF ? 1.0 / (kd - kb) : 0.0;
+    ikp = BF ? 1.0 / (kd + kb) : 0.0;
     const double Idf0 = in.I_df0 * omr * ed0;
     double Iscd0;
     if (BF)
-      Iscd0 = in.I_dr0 * in.t * ((A0 - ed0) / (kd - kb));                    // bf:95
+      Iscd0 = in.I_dr0 * in.t * ((A0 - ed0) * ikm);                          // bf:95
     else
-      Iscd0 = 0.5 * (in.I_dr0 * (1 - rho_c) * exp(-kp * kb * LT) - in.I_dr0 * (1 - sigma) * A0);
+      Iscd0 = 0.5 * (in.I_dr0 * (1 - rho_c) * fexp(-kp * kb * LT) - in.I_dr0 * (1 - sigma) * A0);
     gnd = in.s * (in.I_dr0 * A0 + Idf0 + Iscd0);
     unif = rec[S_UNIF] != 0.0;
     const double dl = rec[S_DL];
-    qd = exp(kd * dl);                       // lai decreases with j
+    qd = fexp(kd * dl);                       // lai decreases with j
     qr = fast_rcp(qd);
-    qx = BF ? qr : exp(kp * kb * dl);
+    qx = BF ? qr : fexp(kp * kb * dl);
     ed = ex = er = 1.0;
   }
   // levels must be visited in ascending order
+  template <int MODE = 2>
   __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) {
     const double L = rec[REC_HDR + j], Asl = rec[REC_HDR + nz + j];
-    if (!unif || exact_level(j)) {
-      ed = exp(-kd * L);
-      ex = BF ? exp(kd * L - (kb + kd) * LT) : exp(-kp * kb * L);
-      er = exp(-kd * (LT - L));
+    if (exact_here<MODE>(unif, j)) {
+      const double u = fexp(hm - kd * L);
+      const double iu = fast_rcp(u);
+      ed = u * cm;
+      er = cm * iu;
+      ex = BF ? cx * iu : fexp(-kp * kb * L);
     } else {
       ed *= qd;
       ex *= qx;
@@ -227,8 +260,8 @@ struct SchG77 {
     const double Idf = I_df0 * omr * ed;                                     // g77:73 / bf:84
     double Iscd, Iscu;
     if (BF) {
-      Iscd = I_dr0 * t * ((Asl - ed) / (kd - kb));                           // bf:95
-      Iscu = I_dr0 * r * ((Asl - ex) / (kd + kb));                           // bf:99-103
+      Iscd = I_dr0 * t * ((Asl - ed) * ikm);                                 // bf:95
+      Iscu = I_dr0 * r * ((Asl - ex) * ikp);                                 // bf:99-103
     } else {
       const double sigma = r + t;
       const double Isc = I_dr0 * omr * ex - I_dr0 * (1 - sigma) * Asl;       // g77:84-86
@@ -245,7 +278,7 @@ struct SchG77 {
     o[0] = idr;
     o[1] = dn;
     o[2] = up;
-    o[3] = idr * invmu + 2 * up + 2 * dn;                                    // :122
+    o[3] = __builtin_fma(idr, invmu, 2 * (up + dn));                         // :122
     o[4] = asl;
     o[5] = ash;
     o[6] = asl + ash;
@@ -308,7 +341,8 @@ struct Sch4s {
   double I0, invmu, LT;
   double p1, p2, p3, p4;  // basis functions at the current level
   double q1p, q1m, q2a, q2b;  // per-level factors for uniform dlai (q2a/q2b: e^{+-lam2 dl}, or cos/sin(lam2 dl))
-  bool unif;
+  double E1L, E2L;            // e^{-lam1 LT}, e^{-lam2 LT}: phi2 = E1L / phi1, phi4 = E2L / phi3 (two exponentials per level, not four)
+  bool unif, direct;          // direct: lam LT so large that 1/phi could overflow -> every exponential evaluated by itself
 
   __device__ inline void init(const double* rec, const BandIn& in, const SolveArgs& a) {
     const double mu_s = a.mu_s;
@@ -361,7 +395,9 @@ struct Sch4s {
     //   real:  phi3 = e^{-lam2 x}, phi4 = e^{-lam2 (L - x)}      osc: phi3 = cos(lam2 x), phi4 = sin(lam2 x)
     const double U1x = 0.5 * (v1x + lam1 * n0 * v1x), U1y = 0.5 * (v1y + lam1 * n1 * v1y);
     const double W1x = 0.5 * (v1x - lam1 * n0 * v1x), W1y = 0.5 * (v1y - lam1 * n1 * v1y);
-    const double E1L = exp(-lam1 * LT);
+    E1L = fexp(-lam1 * LT);
+    E2L = 0.0;
+    direct = lam1 * LT > 600.0 || (!osc && lam2 * LT > 600.0);
     // yd, yu contribution of each basis function: [basis][x=0 | x=L][yd | yu][component]
     double Y[4][2][2][2];
     Y[0][0][0][0] = U1x;       Y[0][0][0][1] = U1y;       Y[0][0][1][0] = W1x;       Y[0][0][1][1] = W1y;
@@ -382,7 +418,7 @@ struct Sch4s {
       Y[3][1][0][0] = hx * sL - qx * cL; Y[3][1][0][1] = hy * sL - qy * cL;
       Y[3][1][1][0] = hx * sL + qx * cL; Y[3][1][1][1] = hy * sL + qy * cL;
     } else {
-      const double E2L = exp(-lam2 * LT);
+      E2L = fexp(-lam2 * LT);
       const double U2x = hx + qx, U2y = hy + qy, W2x = hx - qx, W2y = hy - qy;
       Y[2][0][0][0] = U2x;       Y[2][0][0][1] = U2y;       Y[2][0][1][0] = W2x;       Y[2][0][1][1] = W2y;
       Y[2][1][0][0] = U2x * E2L; Y[2][1][0][1] = U2y * E2L; Y[2][1][1][0] = W2x * E2L; Y[2][1][1][1] = W2y * E2L;
@@ -392,7 +428,7 @@ struct Sch4s {
     // boundary conditions
     //   top    (x = 0): yd = R_df0 [1, 1]                                   (:110-116, both problems summed)
     //   bottom (x = L): yu - rho (2 muv . yd + mu0 R_dr0 e^{-kappa L}) [1, 1] = 0     (:128-138)
-    const double eKL = exp(-kap * LT);
+    const double eKL = fexp(-kap * LT);
     double A[4][5];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -432,29 +468,34 @@ struct Sch4s {
     u[4] = tp * (mu2 * Pu0 + mu1 * Pu1);
     unif = rec[S_UNIF] != 0.0;
     const double dl = rec[S_DL];
-    q1p = exp(lam1 * dl);  // x = lai decreases with j
+    q1p = fexp(lam1 * dl);  // x = lai decreases with j
     q1m = fast_rcp(q1p);
     if (osc) {
       sincos(lam2 * dl, &q2b, &q2a);  // q2a = cos, q2b = sin
     } else {
-      q2a = exp(lam2 * dl);
+      q2a = fexp(lam2 * dl);
       q2b = fast_rcp(q2a);
     }
     p1 = p2 = p3 = p4 = 1.0;
   }
 
   // levels must be visited in ascending order
+  template <int MODE = 2>
   __device__ inline void level(int j, const double* rec, int nz, double (&o)[NARR]) {
     const double x = rec[REC_HDR + j], eK = rec[REC_HDR + nz + j];
-    if (!unif || exact_level(j)) {
-      p1 = exp(-lam1 * x);
-      p2 = exp(-lam1 * (LT - x));
-      if (osc) {
-        sincos(lam2 * x, &p4, &p3);
+    if (exact_here<MODE>(unif, j)) {
+      // both exponentials for every lane, side by side (two independent dependency chains); the few oscillatory lanes (0.3 % of the
+      // synthetic bands, one wave in eight holds one) overwrite the second with sin / cos afterwards
+      p1 = fexp(-lam1 * x);
+      p3 = fexp(-lam2 * x);
+      if (direct) {
+        p2 = fexp(-lam1 * (LT - x));
+        p4 = fexp(-lam2 * (LT - x));
       } else {
-        p3 = exp(-lam2 * x);
-        p4 = exp(-lam2 * (LT - x));
+        p2 = E1L * fast_rcp(p1);
+        p4 = E2L * fast_rcp(p3);
       }
+      if (osc) fast_sincos(lam2 * x, p4, p3);
     } else {
       p1 *= q1p;
       p2 *= q1m;
@@ -467,13 +508,13 @@ struct Sch4s {
         p4 *= q2b;
       }
     }
-    const double dn = d[0] * p1 + d[1] * p2 + d[2] * p3 + d[3] * p4 + d[4] * eK;
-    const double up = u[0] * p1 + u[1] * p2 + u[2] * p3 + u[3] * p4 + u[4] * eK;
+    const double dn = __builtin_fma(d[0], p1, __builtin_fma(d[1], p2, __builtin_fma(d[2], p3, __builtin_fma(d[3], p4, d[4] * eK))));
+    const double up = __builtin_fma(u[0], p1, __builtin_fma(u[1], p2, __builtin_fma(u[2], p3, __builtin_fma(u[3], p4, u[4] * eK))));
     const double idr = I0 * eK;                      // :284
     o[0] = idr;
     o[1] = dn;
     o[2] = up;
-    o[3] = idr * invmu + 2 * up + 2 * dn;            // :290
+    o[3] = __builtin_fma(idr, invmu, 2 * (up + dn));  // :290
   }
 };
 
@@ -617,6 +658,7 @@ struct PipeTileCfg {
   int ncomp;    // compute threads (multiple of 64)
   int T;        // levels per tile
   int rec_dbl;  // doubles reserved for the staged column record
+  int prio;     // s_setprio of the store waves (0 = leave at the default)
 };
 
 template <class S, typename TIO, int MAXT, bool FUSED>
@@ -647,22 +689,32 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
     const int b = active ? tid : 0;
     S st;
     st.init(rec, bin, a);
-    int buf = 0;
-    for (int j0 = 0; j0 < nz; j0 += T) {
-      const int Tc = min(T, nz - j0);
-      TIO* tl = tile + buf * bufrun + b;
-      for (int t = 0; t < Tc; ++t) {
-        double val[S::NARR];
-        st.level(j0 + t, rec, nz, val);
-        if (active) {
+    // (the K0 flag is the same for every lane of the workgroup: read through a scalar register, so that the branch is a scalar one)
+    const bool unif = __builtin_amdgcn_readfirstlane((int)(rec[S_UNIF] != 0.0)) != 0;
+    auto sweep = [&](auto mode) {
+      constexpr int MODE = decltype(mode)::value;
+      int buf = 0;
+      for (int j0 = 0; j0 < nz; j0 += T) {
+        const int Tc = min(T, nz - j0);
+        TIO* tl = tile + buf * bufrun + b;
+        for (int t = 0; t < Tc; ++t) {
+          double val[S::NARR];
+          st.template level<MODE>(j0 + t, rec, nz, val);
+          if (active) {
 #pragma unroll
-          for (int k = 0; k < S::NARR; ++k) tl[k * colrun + t * nb] = (TIO)val[k];
+            for (int k = 0; k < S::NARR; ++k) tl[k * colrun + t * nb] = (TIO)val[k];
+          }
         }
+        lds_barrier();  // tile complete: hand it to the store waves
+        buf ^= 1;
       }
-      lds_barrier();  // tile complete: hand it to the store waves
-      buf ^= 1;
-    }
+    };
+    if (unif)
+      sweep(std::integral_constant<int, 1>{});
+    else
+      sweep(std::integral_constant<int, 0>{});
   } else if constexpr (!FUSED) {
+    if (cfg.prio) __builtin_amdgcn_s_setprio(3);
     // ---- store role, any nb / alignment.  A column is one flat run of nz * nb elements per array, so a round need not stop at a
     // level boundary: it writes every 128-B line that is complete so far.  The part-line behind the last complete line is
     // copied into the head-room in front of the OTHER buffer's tile (memory the compute waves never touch), where the next
@@ -713,6 +765,7 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
     }
   } else {
     // ---- store role: thread -> (row, 16-B vector) walk over the T x nbv vectors of a tile ----
+    if (cfg.prio) __builtin_amdgcn_s_setprio(3);
     const int nbv = nb / VW;
     const int sid = tid - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
     const int dt = nst / nbv, dp = nst - dt * nbv;
@@ -833,6 +886,7 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
     pc.ncomp = pcomp;
     pc.T = Tp;
     pc.rec_dbl = (a.reclen + 1) & ~1;
+    pc.prio = (g_tune[2] & 64) ? 1 : 0;  // tune [2] bit6: store waves at s_setprio 3 (A/B)
     // two tile buffers (the generic flush adds one line of head-room per array and buffer)
     const size_t psh = pc.rec_dbl * sizeof(double) + 2 * plevel * Tp + (fused ? 0 : 2 * S::NARR * 128);
     if (nsw >= 1 && Tp >= 2 && psh <= 160 * 1024 && (fused ? (2 * plevel * Ta <= target || g_tune[4] > 0) : true)) {

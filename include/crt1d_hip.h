@@ -279,6 +279,10 @@ const char* crt_hip_last_kernel(void);
 /* bandwidth probes used by bench.py to report a measured HBM ceiling next to the 8 TB/s spec */
 int crt_hip_probe_fill_f64(double* dst, size_t n, double value, crt_stream_t stream);
 int crt_hip_probe_copy_f64(double* dst, const double* src, size_t n, crt_stream_t stream);
+/* The device math the solve kernels use in place of libm: e[i] = exp(x[i]) (18 instructions, <= 1 ulp), sn / cs[i] = sin / cos(x[i])
+ * (two-term Cody-Waite reduction, absolute error ~2e-16 for |x| < 1e6; the oscillatory modes of solve_4s).  Diagnostic: lets a test
+ * bound their error against the host's libm, which is what the reference's numpy.exp calls (_solve_2s.py:125-131). */
+int crt_hip_probe_math_f64(const double* x, size_t n, double* e, double* sn, double* cs, crt_stream_t stream);
 /* The flush of the solve kernels alone: workgroup c writes column c (col_doubles doubles) of all `narrays` arrays in step, run_doubles at a
  * time (T levels x nb bands), with 16-byte streaming stores.  On a set from crt_hip_buffer_alloc_set it measures the store rate that
  * placement allows; it OVERWRITES the arrays with `value`.  No counterpart in the reference. */

@@ -7,7 +7,7 @@
 # The program follows `--` directly (python3 <script>); no traces are combined with --pmc.  Output: gpurun_out/prof_<tag>/<case>/<pass>/.
 # usage: bash tools/profile_round.sh <tag> [case-name-filter]
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r02}
+TAG=${1:-r03}
 ONLY=${2:-}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -46,6 +46,17 @@ CASES=(
 "zq_pa_nz100|wf|$R/bench.py --scheme zq_pa --nz 100 --ncol 6000 $B"
 "n79_nz100|wf|$R/bench.py --scheme n79 --nz 100 --ncol 6000 $B"
 "zq_pa_nb107|wfsq|$R/bench.py --scheme zq_pa --nb 107 --ncol 30000 $B"
+# non-uniform dLAI (any strictly decreasing lai is legal input, crt1d/model.py:240-246): none of the uniform-column fast paths applies
+"2s_ragged|wfsq|$R/bench.py --scheme 2s --ragged $B"
+"4s_ragged|wfsqi|$R/bench.py --scheme 4s --ragged $B"
+"bl_ragged|wf|$R/bench.py --scheme bl --ragged $B"
+"g77_ragged|wfsq|$R/bench.py --scheme g77 --ragged $B"
+"bf_ragged|wfsq|$R/bench.py --scheme bf --ragged $B"
+"n79_ragged|wfsq|$R/bench.py --scheme n79 --ragged $B"
+"zq_ragged|wf|$R/bench.py --scheme zq --ragged $B"
+"zq_pa_ragged|wf|$R/bench.py --scheme zq_pa --ragged $B"
+"zq_nz100_ragged|wf|$R/bench.py --scheme zq --nz 100 --ncol 6000 --ragged $B"
+"n79_nz100_ragged|wfsq|$R/bench.py --scheme n79 --nz 100 --ncol 6000 --ragged $B"
 )
 for entry in "${CASES[@]}"; do
   IFS='|' read -r name passes cmd <<< "$entry"
