@@ -376,11 +376,13 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
           isl = 1.0 / (fs * dl);                                                // :154
           ish = 1.0 / ((1.0 - fs) * dl);                                        // :155
         }
-        v[nz + j] = tb;
+        // what the level loops multiply by, formed once per column (tri_schemes.hpp, TriN79): 1 - tb, fs / (fs dlai), 1 / (fs dlai),
+        // (1 - fs) / ((1 - fs) dlai)
+        v[nz + j] = 1.0 - tb;
         v[2 * nz + j] = td;
-        v[3 * nz + j] = fs;
+        v[3 * nz + j] = fs * isl;
         v[4 * nz + j] = isl;
-        v[5 * nz + j] = ish;
+        v[5 * nz + j] = (1.0 - fs) * ish;
         v[6 * nz + j] = 1.0 / (1.0 - td);  // refld = (1 - td) rho  ->  1/refld = (1/rho) * this
         break;
       }

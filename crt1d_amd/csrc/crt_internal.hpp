@@ -15,7 +15,7 @@ namespace crt {
 //   vectors (by scheme):
 //     2s, 4s, g77, bf : lai, ekl = exp(-K_b lai)
 //     bl              : lai, ekl, tau_d(lai_j)                       (_solve_bl.py:31-37)
-//     n79             : tbcum = ekl, tb, td, fracsun, 1/(fracsun dlai), 1/(fracsha dlai), 1/(1 - td)
+//     n79             : tbcum = ekl, 1 - tb, td, fracsun/(fracsun dlai), 1/(fracsun dlai), fracsha/(fracsha dlai), 1/(1 - td)
 //                                                                     (_solve_n79.py:40-59)
 //     zq              : ekl                                           (_solve_zq.py:130)
 //     zq_pa           : beam fraction on the M computational layers, ekl, interpolation index, weight

@@ -658,7 +658,6 @@ struct PipeTileCfg {
   int ncomp;    // compute threads (multiple of 64)
   int T;        // levels per tile
   int rec_dbl;  // doubles reserved for the staged column record
-  int prio;     // s_setprio of the store waves (0 = leave at the default)
 };
 
 template <class S, typename TIO, int MAXT, bool FUSED>
@@ -667,15 +666,23 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
   typedef TIO vt __attribute__((ext_vector_type(VW)));
   extern __shared__ double lds[];
   const int nb = a.nb, nz = a.nz, T = cfg.T;
-  const int tid = threadIdx.x;
   const int c = blockIdx.x;
+  const int tid = threadIdx.x;
+#ifdef CRT_STAMP
+  if ((threadIdx.x & 63) == 0) {  // where the hardware put this wave (SIMD id = HW_ID[5:4]; LDS base / size in 256-B granules)
+    double* dbg = const_cast<double*>(a.ws) + (long long)c * a.reclen + 100 + 3 * (threadIdx.x >> 6);
+    dbg[0] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID, all 32 bits
+    dbg[1] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 6);   // HW_REG_LDS_ALLOC
+    dbg[2] = (double)(tid >> 6);
+  }
+#endif
   // the band's spectra are requested together with the column record (not after the barrier that publishes it): one round trip
   // instead of two before the first level can be formed
   BandIn bin = {};
   if (tid < cfg.ncomp) bin = load_band<TIO>(a, c, tid < nb ? tid : 0, S::SOIL);
   {
     const double* src = a.ws + (long long)c * a.reclen;
-    for (int i = tid; i < a.reclen; i += blockDim.x) lds[i] = src[i];
+    for (int i = threadIdx.x; i < a.reclen; i += blockDim.x) lds[i] = src[i];
   }
   __syncthreads();
   const double* rec = lds;
@@ -687,8 +694,20 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
     // ---- compute role ----
     const bool active = tid < nb;
     const int b = active ? tid : 0;
+#ifdef CRT_STAMP
+    // diagnostic build only (tools/stamp_timeline.py): wall_clock64 stamps of compute wave 0 / store wave 0 of every workgroup, written
+    // over the column's own K0 record in the workspace (already staged in LDS; K0 rewrites it) -- never into an output
+    double* stamp = const_cast<double*>(a.ws) + (long long)c * a.reclen;
+    int nstamp = 0;
+    const bool stamper = tid == 0;
+#define STAMP() do { if (stamper && nstamp < 60) stamp[nstamp++] = (double)wall_clock64(); } while (0)
+    STAMP();
+#else
+#define STAMP() do {} while (0)
+#endif
     S st;
     st.init(rec, bin, a);
+    STAMP();
     // (the K0 flag is the same for every lane of the workgroup: read through a scalar register, so that the branch is a scalar one)
     const bool unif = __builtin_amdgcn_readfirstlane((int)(rec[S_UNIF] != 0.0)) != 0;
     auto sweep = [&](auto mode) {
@@ -705,7 +724,9 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
             for (int k = 0; k < S::NARR; ++k) tl[k * colrun + t * nb] = (TIO)val[k];
           }
         }
+        STAMP();
         lds_barrier();  // tile complete: hand it to the store waves
+        STAMP();
         buf ^= 1;
       }
     };
@@ -714,7 +735,6 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
     else
       sweep(std::integral_constant<int, 0>{});
   } else if constexpr (!FUSED) {
-    if (cfg.prio) __builtin_amdgcn_s_setprio(3);
     // ---- store role, any nb / alignment.  A column is one flat run of nz * nb elements per array, so a round need not stop at a
     // level boundary: it writes every 128-B line that is complete so far.  The part-line behind the last complete line is
     // copied into the head-room in front of the OTHER buffer's tile (memory the compute waves never touch), where the next
@@ -765,15 +785,23 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
     }
   } else {
     // ---- store role: thread -> (row, 16-B vector) walk over the T x nbv vectors of a tile ----
-    if (cfg.prio) __builtin_amdgcn_s_setprio(3);
     const int nbv = nb / VW;
     const int sid = tid - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
     const int dt = nst / nbv, dp = nst - dt * nbv;
     const int t0 = sid / nbv, p0 = sid - t0 * nbv;
+#ifdef CRT_STAMP
+    double* sstamp = const_cast<double*>(a.ws) + (long long)c * a.reclen + 64;
+    int nsstamp = 0;
+#define SSTAMP() do { if (sid == 0 && nsstamp < 60) sstamp[nsstamp++] = (double)wall_clock64(); } while (0)
+#else
+#define SSTAMP() do {} while (0)
+#endif
+    SSTAMP();
     int buf = 0;
     for (int j0 = 0; j0 < nz; j0 += T) {
       const int Tc = min(T, nz - j0);
       lds_barrier();  // tile `buf` is complete
+      SSTAMP();
       const vt* tv = reinterpret_cast<const vt*>(tile + buf * bufrun);
       int t = t0, p = p0;
       while (t < Tc) {
@@ -790,8 +818,13 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
           ++t;
         }
       }
+      SSTAMP();
       buf ^= 1;
     }
+#ifdef CRT_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SSTAMP();  // every store of the column acknowledged
+#endif
   }
 }
 
@@ -886,7 +919,6 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
     pc.ncomp = pcomp;
     pc.T = Tp;
     pc.rec_dbl = (a.reclen + 1) & ~1;
-    pc.prio = (g_tune[2] & 64) ? 1 : 0;  // tune [2] bit6: store waves at s_setprio 3 (A/B)
     // two tile buffers (the generic flush adds one line of head-room per array and buffer)
     const size_t psh = pc.rec_dbl * sizeof(double) + 2 * plevel * Tp + (fused ? 0 : 2 * S::NARR * 128);
     if (nsw >= 1 && Tp >= 2 && psh <= 160 * 1024 && (fused ? (2 * plevel * Ta <= target || g_tune[4] > 0) : true)) {

@@ -52,14 +52,18 @@ struct TriN79 {
     irho = fast_rcp(rho);
     invmu = rec[S_INVMU];
   }
+  // K0 vectors of the record (colpre.hip): [0] tbcum = e^{-K_b lai}, [1] 1 - tb, [2] td, [3] fs / (fs dlai), [4] 1 / (fs dlai),
+  // [5] (1 - fs) / ((1 - fs) dlai), [6] 1 / (1 - td).  Explicit FMAs throughout (the build runs with -ffp-contract=off): the sweeps are
+  // dependency chains, every fused pair is one step less on them.
   // layer scattering coefficients (:85-88 / :102-105): r = trand/refld, s = refld - trand^2/refld.
   // 1/refld = (1/rho) * 1/(1 - td_j): a per-band register times a per-level K0 vector, no division here.
   __device__ inline void layer(const double* rec, int nz, int j, double& r, double& s) const {
     const double t = rec[REC_HDR + 2 * nz + j];
-    const double refld = (1 - t) * rho;
-    const double trand = (1 - t) * tau + t;
+    const double omt = 1 - t;
+    const double refld = omt * rho;
+    const double trand = __builtin_fma(omt, tau, t);
     r = trand * (irho * rec[REC_HDR + 6 * nz + j]);
-    s = refld - trand * r;
+    s = __builtin_fma(-trand, r, refld);
   }
   __device__ inline void first(const double* rec, int nz, double& e, double& f) const {
     e = -alb;  // row 0: soil, upward (:79-82)
@@ -71,7 +75,7 @@ struct TriN79 {
   //   e' = -s_k A / D,   f' = (d_even A + r_k (d_odd + s_m f)) / D.     (|r r| >> |A|: no cancellation in D)
   __device__ inline void advance(int k, const double* rec, int nz, double& e, double& f) const {
     const double* tbcum = rec + REC_HDR;
-    const double* tb = tbcum + nz;
+    const double* omtb = tbcum + nz;
     const int mk = k == 0 ? 1 : k;  // the first downward row uses layer index 1 (:85-92), as the reference
     double rm, sm, r, s;
     layer(rec, nz, mk, rm, sm);
@@ -82,17 +86,17 @@ struct TriN79 {
       s = sm;
     }
     const double src = swb * tbcum[k + 1];
-    const double d_odd = src * (1 - tb[mk]) * (tau - rho * rm);   // (:92, :119)
-    const double d_even = src * (1 - tb[k]) * (rho - tau * r);    // (:109, :129)
-    const double A = 1 + sm * e;
-    const double iD = fast_rcp(A - r * rm);
+    const double d_odd = (src * omtb[mk]) * __builtin_fma(-rho, rm, tau);   // (:92, :119)
+    const double d_even = (src * omtb[k]) * __builtin_fma(-tau, r, rho);    // (:109, :129)
+    const double A = __builtin_fma(sm, e, 1.0);
+    const double iD = fast_rcp(__builtin_fma(-r, rm, A));
     e = -s * A * iD;
-    f = (d_even * A + r * (d_odd + sm * f)) * iD;
+    f = __builtin_fma(d_even, A, r * __builtin_fma(sm, f, d_odd)) * iD;
   }
   // top even row (k = nz-1): dn = sky diffuse (:132-135); emits output level nz-1 (no layer above it)
   __device__ inline void top(const double* rec, int nz, double e, double f, double (&o)[NST]) {
     dn = swd;
-    up = f - e * dn;
+    up = __builtin_fma(-e, dn, f);
     o[0] = dn;
     o[1] = up;
     o[2] = 0.0;
@@ -101,22 +105,23 @@ struct TriN79 {
   // level k from level k+1; emits output level k and layer k
   __device__ inline void back(int k, const double* rec, int nz, double e, double f, double (&o)[NST]) {
     const double* tbcum = rec + REC_HDR;
-    const double* tb = tbcum + nz;
     const double t = rec[REC_HDR + 2 * nz + k];
-    const double refld = (1 - t) * rho;
-    const double trand = (1 - t) * tau + t;
-    const double src = swb * tbcum[k + 1] * (1 - tb[k]);
+    const double omt = 1 - t;
+    const double refld = omt * rho;
+    const double trand = __builtin_fma(omt, tau, t);
+    const double src = swb * tbcum[k + 1] * rec[REC_HDR + nz + k];
     const double dn1 = dn;
     // dn_k from the upward equation of level k+1 (layer k):  -r dn_k + up_{k+1} - s dn_{k+1} = d
-    dn = (refld * up + (trand * trand - refld * refld) * dn1 - src * (rho * refld - tau * trand)) * fast_rcp(trand);
-    up = f - e * dn;
+    const double k_dn = __builtin_fma(trand, trand, -(refld * refld));
+    const double k_src = __builtin_fma(rho, refld, -(tau * trand));
+    dn = __builtin_fma(refld, up, __builtin_fma(k_dn, dn1, -(src * k_src))) * fast_rcp(trand);
+    up = __builtin_fma(-e, dn, f);
     const double direct = src * oma;                       // :145
-    const double diffuse = (dn1 + up) * (1 - t) * oma;     // :146
-    const double fs = rec[REC_HDR + 3 * nz + k];
+    const double diffuse = (dn1 + up) * (omt * oma);       // :146
     o[0] = dn;
     o[1] = up;
-    o[2] = (diffuse * fs + direct) * rec[REC_HDR + 4 * nz + k];  // :154
-    o[3] = (diffuse * (1 - fs)) * rec[REC_HDR + 5 * nz + k];     // :155
+    o[2] = __builtin_fma(diffuse, rec[REC_HDR + 3 * nz + k], direct * rec[REC_HDR + 4 * nz + k]);  // :154  (diffuse fs + direct) / (fs dlai)
+    o[3] = diffuse * rec[REC_HDR + 5 * nz + k];                                                    // :155  diffuse (1 - fs) / ((1 - fs) dlai)
   }
   // value of output array `arr` at tile row t (level j), band b; st[] = staged arrays at that element
   template <int ARR>
@@ -159,36 +164,35 @@ struct TriN79U : TriN79 {
     const int nz = a.nz;
     layer(rec, nz, 1, r, s);
     rr = r * r;
-    const double tb = rec[REC_HDR + nz + 1], t = rec[REC_HDR + 2 * nz + 1];
-    omtb = 1 - tb;
-    k_odd = omtb * (tau - rho * r);   // (:92, :119)
-    k_even = omtb * (rho - tau * r);  // (:109, :129)
+    const double t = rec[REC_HDR + 2 * nz + 1];
+    omtb = rec[REC_HDR + nz + 1];
+    k_odd = omtb * __builtin_fma(-rho, r, tau);   // (:92, :119)
+    k_even = omtb * __builtin_fma(-tau, r, rho);  // (:109, :129)
     refld = (1 - t) * rho;
-    const double trand = (1 - t) * tau + t;
+    const double trand = __builtin_fma(1 - t, tau, t);
     itrand = fast_rcp(trand);
-    k_dn = trand * trand - refld * refld;
-    k_src = omtb * (rho * refld - tau * trand);
+    k_dn = __builtin_fma(trand, trand, -(refld * refld));
+    k_src = omtb * __builtin_fma(rho, refld, -(tau * trand));
     omt_oma = (1 - t) * oma;
   }
   __device__ inline void advance(int k, const double* rec, int nz, double& e, double& f) const {
     const double src = swb * rec[REC_HDR + k + 1];
-    const double A = 1 + s * e;
+    const double A = __builtin_fma(s, e, 1.0);
     const double iD = fast_rcp(A - rr);
     e = -s * A * iD;
-    f = (src * k_even * A + r * (src * k_odd + s * f)) * iD;
+    f = __builtin_fma(src * k_even, A, r * __builtin_fma(s, f, src * k_odd)) * iD;
   }
   __device__ inline void back(int k, const double* rec, int nz, double e, double f, double (&o)[NST]) {
     const double src = swb * rec[REC_HDR + k + 1];
     const double dn1 = dn;
-    dn = (refld * up + k_dn * dn1 - src * k_src) * itrand;
-    up = f - e * dn;
+    dn = __builtin_fma(refld, up, __builtin_fma(k_dn, dn1, -(src * k_src))) * itrand;
+    up = __builtin_fma(-e, dn, f);
     const double direct = src * omtb * oma;         // :145
     const double diffuse = (dn1 + up) * omt_oma;    // :146
-    const double fs = rec[REC_HDR + 3 * nz + k];
     o[0] = dn;
     o[1] = up;
-    o[2] = (diffuse * fs + direct) * rec[REC_HDR + 4 * nz + k];  // :154
-    o[3] = (diffuse * (1 - fs)) * rec[REC_HDR + 5 * nz + k];     // :155
+    o[2] = __builtin_fma(diffuse, rec[REC_HDR + 3 * nz + k], direct * rec[REC_HDR + 4 * nz + k]);  // :154
+    o[3] = diffuse * rec[REC_HDR + 5 * nz + k];                                                    // :155
   }
 };
 
@@ -247,19 +251,19 @@ struct TriZq {
     const double S = I_dr0 * rec[REC_HDR + li - 1];  // :130
     const double qlo = (li == 1) ? q0 : q;
     const double qhi = (li == m) ? 0.0 : q;
-    const double dlo = 1 - qlo * q;  // :118
-    const double dhi = 1 - q * qhi;  // :119
+    const double dlo = __builtin_fma(-qlo, q, 1.0);  // :118
+    const double dhi = __builtin_fma(-q, qhi, 1.0);  // :119
     const double C1 = dlo * cu * S;
     const double C2 = dhi * cd * S;
     const double B = fwd * (e - qlo);
-    const double iD = fast_rcp(qhi * fwd * B + dhi * dlo);
+    const double iD = fast_rcp(__builtin_fma(qhi * fwd, B, dhi * dlo));
     e = fwd * B * iD;
-    f = (dhi * (C1 + fwd * f) - C2 * B) * iD;
+    f = __builtin_fma(dhi, __builtin_fma(fwd, f, C1), -(C2 * B)) * iD;
   }
   // k = m: x[2m+1] = I_df0 (:122,143); no output row at k = m
   __device__ inline void top(const double* rec, int m, double e, double f, double (&o)[NST]) {
     xd = I_df0;
-    xu = f - e * xd;
+    xu = __builtin_fma(-e, xd, f);
     o[0] = o[1] = o[2] = o[3] = 0.0;
   }
   __device__ inline void back(int k, const double* rec, int m, double e, double f, double (&o)[NST]) {
@@ -267,16 +271,16 @@ struct TriZq {
     const double S = I_dr0 * rec[REC_HDR + k];
     const double qlo = (li == 1) ? q0 : q;
     const double qhi = (li == m) ? 0.0 : q;
-    const double dhi = 1 - q * qhi;
-    const double dlo = 1 - qlo * q;
+    const double dhi = __builtin_fma(-q, qhi, 1.0);
+    const double dlo = __builtin_fma(-qlo, q, 1.0);
     // SWd0[li-1] from the original row 2li:  dhi x_{2li-1} - qhi fwd x_{2li} - fwd x_{2li+1} = C
     // (1/dhi and 1/dlo take three values per band; keeping them in registers costs the integrated kernel a wave of
     // occupancy -- 96 -> 98 VGPRs, 1.19 -> 1.45 ms -- and the profile kernels are store-bound, so they are recomputed)
-    const double xdl = (dhi * cd * S + qhi * fwd * xu + fwd * xd) * fast_rcp(dhi);
-    const double xul = f - e * xdl;  // SWu0[li-1]
+    const double xdl = __builtin_fma(dhi * cd, S, fwd * __builtin_fma(qhi, xu, xd)) * fast_rcp(dhi);
+    const double xul = __builtin_fma(-e, xdl, f);  // SWu0[li-1]
     const double iden = fast_rcp(dlo);   // multiple-scattering correction, eqs. 24/25 (:180-187)
-    o[0] = (xd + q * xul) * iden;
-    o[1] = (xul + qlo * xd) * iden;
+    o[0] = __builtin_fma(q, xul, xd) * iden;
+    o[1] = __builtin_fma(qlo, xd, xul) * iden;
     o[2] = xd;   // I_df_d_ss :197
     o[3] = xul;  // I_df_u_ss :199
     xd = xdl;
