@@ -69,6 +69,16 @@ class CrtOutputs(ctypes.Structure):
     _fields_ = [(k, _vp) for k in ("I_dr", "I_df_d", "I_df_u", "F", "x0", "x1", "x2")]
 
 
+class CrtBandsumOut(ctypes.Structure):
+    """``crt_bandsum_out``: layer-absorption band sums (+ ``totals``), and -- optional, all six or none -- the direct-beam part and the
+    band-integrated level profiles of every irradiance variable ``diagnostics.band`` reduces."""
+
+    _fields_ = [(k, _vp) for k in ("aI", "aI_sl", "aI_sh", "totals", "aI_dr", "I_dr", "I_df_d", "I_df_u", "F", "I_d")]
+
+
+ABI_VERSION = 3
+
+
 EXPORTS = [
     "crt_hip_abi_version",
     "crt_hip_strerror",
@@ -94,8 +104,11 @@ EXPORTS = [
     "crt_hip_bf_f32",
     "crt_hip_zq_pa_f32",
     "crt_hip_absorb_bandsum_f64",
+    "crt_hip_absorb_bandsum2_f64",
     "crt_hip_integrated_f64",
+    "crt_hip_integrated2_f64",
     "crt_hip_absorb_f64",
+    "crt_hip_band_reduce_f64",
     "crt_hip_tau_d_f64",
     "crt_hip_smear_tuv_f64",
     "crt_hip_lai_beta_f64",
@@ -173,6 +186,17 @@ def load():
         ctypes.c_int, ctypes.POINTER(CrtColumns), ctypes.POINTER(CrtBands), ctypes.POINTER(CrtOptions), _vp, ctypes.c_int32,
         _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp,
     ]
+    lib.crt_hip_absorb_bandsum2_f64.restype = ctypes.c_int
+    lib.crt_hip_absorb_bandsum2_f64.argtypes = [
+        ctypes.POINTER(CrtColumns), ctypes.POINTER(CrtBands), _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.POINTER(CrtBandsumOut), _vp,
+    ]
+    lib.crt_hip_integrated2_f64.restype = ctypes.c_int
+    lib.crt_hip_integrated2_f64.argtypes = [
+        ctypes.c_int, ctypes.POINTER(CrtColumns), ctypes.POINTER(CrtBands), ctypes.POINTER(CrtOptions), _vp, ctypes.c_int32,
+        ctypes.POINTER(CrtBandsumOut), _vp, ctypes.c_size_t, _vp,
+    ]
+    lib.crt_hip_band_reduce_f64.restype = ctypes.c_int
+    lib.crt_hip_band_reduce_f64.argtypes = [_vp, ctypes.c_int64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp]
     lib.crt_hip_absorb_f64.restype = ctypes.c_int
     lib.crt_hip_absorb_f64.argtypes = [ctypes.POINTER(CrtColumns), ctypes.POINTER(CrtBands), _vp, _vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp]
     lib.crt_hip_tau_d_f64.restype = ctypes.c_int
@@ -205,7 +229,7 @@ def load():
     lib.crt_hip_probe_math_f64.argtypes = [_vp, ctypes.c_size_t, _vp, _vp, _vp, _vp]
     lib.crt_hip_probe_store_set_f64.restype = ctypes.c_int
     lib.crt_hip_probe_store_set_f64.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, _vp]
-    if lib.crt_hip_abi_version() != 2:
+    if lib.crt_hip_abi_version() != ABI_VERSION:
         raise HipLibraryMissing(f"{LIB_PATH}: ABI version mismatch, rebuild")
     _lib = lib
     return lib

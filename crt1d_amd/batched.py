@@ -477,11 +477,31 @@ def _check_epilogue_inputs(cols, bands, sol):
 
 
 BANDSUM_KEYS = ("aI", "aI_sl", "aI_sh", "totals")
+# with ``profiles=True``: the direct-beam part of the absorption and the band-integrated LEVEL profiles of every irradiance variable
+# ``diagnostics.band`` reduces (crt1d/diagnostics.py:84-91; the "I..." / "F" variables of ``Model.to_xr``, model.py:421-426)
+PROFILE_KEYS = ("aI_dr", "I_dr", "I_df_d", "I_df_u", "F", "I_d")
 
 
-def bandsum_shapes(ncol, nz, ngroup):
-    """Shapes of the integrated outputs, in ``BANDSUM_KEYS`` order."""
-    return {"aI": (ncol, nz - 1, ngroup), "aI_sl": (ncol, nz - 1, ngroup), "aI_sh": (ncol, nz - 1, ngroup), "totals": (ncol, ngroup, 4)}
+def bandsum_shapes(ncol, nz, ngroup, profiles=False):
+    """Shapes of the integrated outputs, in ``BANDSUM_KEYS`` (+ ``PROFILE_KEYS``) order."""
+    sh = {"aI": (ncol, nz - 1, ngroup), "aI_sl": (ncol, nz - 1, ngroup), "aI_sh": (ncol, nz - 1, ngroup), "totals": (ncol, ngroup, 4)}
+    if profiles:
+        sh["aI_dr"] = (ncol, nz - 1, ngroup)
+        for k in PROFILE_KEYS[1:]:
+            sh[k] = (ncol, nz, ngroup)
+    return sh
+
+
+def _bandsum_out_struct(out, profiles):
+    keys = BANDSUM_KEYS + (PROFILE_KEYS if profiles else ())
+    return _lib.CrtBandsumOut(**{k: out[k].data_ptr() for k in keys})
+
+
+def absorption_from_bandsums(res):
+    """The seven entries of the reference's absorption dict (``model.py:637-647``), band-integrated, from a ``profiles=True`` result:
+    ``aI_df = aI - aI_dr``, ``aI_df_sl = aI_sl - aI_dr``, ``aI_df_sh = aI_sh`` (``model.py:628-634``)."""
+    return {"aI": res["aI"], "aI_dr": res["aI_dr"], "aI_df": res["aI"] - res["aI_dr"], "aI_sl": res["aI_sl"], "aI_sh": res["aI_sh"],
+            "aI_df_sl": res["aI_sl"] - res["aI_dr"], "aI_df_sh": res["aI_sh"]}
 
 
 class BandSumPlan:
@@ -489,7 +509,7 @@ class BandSumPlan:
     no allocation and no host synchronisation.  ``out`` may hold caller-owned output tensors (e.g. views into one packed
     message buffer, :class:`crt1d_amd.dist.BandShardPlan`)."""
 
-    def __init__(self, cols: Columns, bands: Bands, sol, band_w, out=None):
+    def __init__(self, cols: Columns, bands: Bands, sol, band_w, out=None, profiles=False):
         self.lib = _lib.load()
         band_w = _f64(band_w, "band_w")
         if band_w.ndim == 1:
@@ -499,33 +519,36 @@ class BandSumPlan:
         _check_epilogue_inputs(cols, bands, sol)
         if band_w.shape[1] != bands.nb or not 1 <= ng <= 4 or band_w.device != dev:
             raise ValueError(f"band_w must be (ngroup <= 4, nb = {bands.nb}) on {dev}")
-        shapes = bandsum_shapes(ncol, nz, ng)
+        shapes = bandsum_shapes(ncol, nz, ng, profiles)
         if out is None:
-            out = {k: torch.empty(shapes[k], dtype=torch.float64, device=dev) for k in BANDSUM_KEYS}
+            out = {k: torch.empty(sh, dtype=torch.float64, device=dev) for k, sh in shapes.items()}
         else:
-            for k in BANDSUM_KEYS:
-                _check_profile(out[k], f"out[{k!r}]", shapes[k], dev)
-        self.cols, self.bands, self.sol, self.band_w, self.out, self.ng = cols, bands, sol, band_w, out, ng
+            for k, sh in shapes.items():
+                _check_profile(out[k], f"out[{k!r}]", sh, dev)
+        self.cols, self.bands, self.sol, self.band_w, self.out, self.ng, self.profiles = cols, bands, sol, band_w, out, ng, profiles
         self._c, self._b = cols.c_struct(), bands.c_struct(ncol)
+        self._o = _bandsum_out_struct(out, profiles)
 
     def __call__(self, stream=None):
         dev = self.cols.device
         s = torch.cuda.current_stream(dev) if stream is None else stream
-        o, sol = self.out, self.sol
+        sol = self.sol
         with torch.cuda.device(dev):
-            st = self.lib.crt_hip_absorb_bandsum_f64(
+            st = self.lib.crt_hip_absorb_bandsum2_f64(
                 ctypes.byref(self._c), ctypes.byref(self._b), sol["I_dr"].data_ptr(), sol["I_df_d"].data_ptr(), sol["I_df_u"].data_ptr(),
-                self.band_w.data_ptr(), self.ng, o["aI"].data_ptr(), o["aI_sl"].data_ptr(), o["aI_sh"].data_ptr(), o["totals"].data_ptr(),
-                s.cuda_stream)
-        _lib.check(st, "crt_hip_absorb_bandsum_f64")
+                self.band_w.data_ptr(), self.ng, ctypes.byref(self._o), s.cuda_stream)
+        _lib.check(st, "crt_hip_absorb_bandsum2_f64")
         return self.out
 
 
-def absorb_bandsum(cols: Columns, bands: Bands, sol, band_w, out=None):
+def absorb_bandsum(cols: Columns, bands: Bands, sol, band_w, out=None, profiles=False):
     """Layer absorption (``model.py:573-647``) reduced over bands with weights ``band_w (ngroup, nb)``
     (``diagnostics.py:39-108``).  Returns ``aI, aI_sl, aI_sh`` ``(ncol, nz-1, ngroup)`` and the
-    energy-balance terms ``totals (ncol, ngroup, 4)`` = incoming, reflected, transmitted, soil-reflected."""
-    return dict(BandSumPlan(cols, bands, sol, band_w, out=out)())
+    energy-balance terms ``totals (ncol, ngroup, 4)`` = incoming, reflected, transmitted, soil-reflected.
+    ``profiles=True`` adds everything else ``diagnostics.band`` returns (``PROFILE_KEYS``): the band-integrated level profiles
+    ``I_dr, I_df_d, I_df_u, F, I_d (ncol, nz, ngroup)`` and ``aI_dr (ncol, nz-1, ngroup)`` (:func:`absorption_from_bandsums`).
+    Photon-flux variants (``calc_PFD``) are a choice of weights: ``spectra.band_weights(..., wl=..., pfd=True)``."""
+    return dict(BandSumPlan(cols, bands, sol, band_w, out=out, profiles=profiles)())
 
 
 ABSORPTION_KEYS = ("aI", "aI_df", "aI_dr", "aI_sh", "aI_sl", "aI_df_sl", "aI_df_sh")  # model.py:637-647
@@ -557,7 +580,8 @@ class IntegratedPlan:
     """Fused solve + absorption + band integrals (``crt_hip_integrated_f64``): no profile ever reaches HBM.
     Outputs as :func:`absorb_bandsum`: ``aI, aI_sl, aI_sh (ncol, nz-1, ngroup)``, ``totals (ncol, ngroup, 4)``."""
 
-    def __init__(self, scheme, cols: Columns, bands: Bands, band_w, *, mu_s=0.501, tau_d_method="quad", workspace=None, out=None):
+    def __init__(self, scheme, cols: Columns, bands: Bands, band_w, *, mu_s=0.501, tau_d_method="quad", workspace=None, out=None,
+                 profiles=False):
         if scheme not in _lib.SCHEME_IDS or scheme == "zq_pa":
             raise ValueError(f"scheme {scheme!r} has no integrated kernel")
         if tau_d_method not in _lib.TAU_D_METHODS:
@@ -573,13 +597,15 @@ class IntegratedPlan:
             raise ValueError("band_w must be (ngroup <= 4, nb)")
         self.band_w = band_w
         ncol, nz, ng, dev = cols.ncol, cols.nz, band_w.shape[0], cols.device
-        shapes = bandsum_shapes(ncol, nz, ng)
+        shapes = bandsum_shapes(ncol, nz, ng, profiles)
         if out is None:
-            out = {k: torch.empty(shapes[k], dtype=torch.float64, device=dev) for k in BANDSUM_KEYS}
+            out = {k: torch.empty(sh, dtype=torch.float64, device=dev) for k, sh in shapes.items()}
         else:
-            for k in BANDSUM_KEYS:
-                _check_profile(out[k], f"out[{k!r}]", shapes[k], dev)
+            for k, sh in shapes.items():
+                _check_profile(out[k], f"out[{k!r}]", sh, dev)
         self.out = out
+        self.profiles = profiles
+        self._out = _bandsum_out_struct(out, profiles)
         cols.check_tables()
         _check_band_device(bands, dev)
         if band_w.device != dev:
@@ -597,13 +623,12 @@ class IntegratedPlan:
         dev = self.cols.device
         s = torch.cuda.current_stream(dev) if stream is None else stream
         self._o.flags = int(flags)
-        o = self.out
         with torch.cuda.device(dev):
-            st = self.lib.crt_hip_integrated_f64(
+            st = self.lib.crt_hip_integrated2_f64(
                 _lib.SCHEME_IDS[self.scheme], ctypes.byref(self._c), ctypes.byref(self._b), ctypes.byref(self._o), self.band_w.data_ptr(),
-                self.band_w.shape[0], o["aI"].data_ptr(), o["aI_sl"].data_ptr(), o["aI_sh"].data_ptr(), o["totals"].data_ptr(),
-                self.workspace.data_ptr(), self.workspace.numel() * self.workspace.element_size(), s.cuda_stream)
-        _lib.check(st, "crt_hip_integrated_f64")
+                self.band_w.shape[0], ctypes.byref(self._out), self.workspace.data_ptr(),
+                self.workspace.numel() * self.workspace.element_size(), s.cuda_stream)
+        _lib.check(st, "crt_hip_integrated2_f64")
         return self.out
 
 

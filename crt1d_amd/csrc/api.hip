@@ -45,9 +45,35 @@ struct EpiArgs {
   double* aI_sl;
   double* aI_sh;
   double* totals;
+  // optional (crt_bandsum_out): the direct-beam part of the absorption [ncol][nz-1][ngroup], and the band-integrated LEVEL profiles
+  // [ncol][nz][ngroup] of every irradiance variable diagnostics.band sums (diagnostics.py:84-91): I_dr, I_df_d, I_df_u, F, I_d
+  double* aI_dr;
+  double* L_dr;
+  double* L_dn;
+  double* L_up;
+  double* L_F;
+  double* L_Id;
 };
 
-template <int MAXT>
+// level outputs from the three level sums: F = I_dr / mu + 2 I_df_u + 2 I_df_d is linear in the profiles (every scheme forms its F this
+// way, e.g. _solve_2s.py:156), so its band sum is the same combination of the band sums; I_d = I_dr + I_df_d (model.py:425)
+__device__ inline void store_level_profiles(const EpiArgs& a, long long o, double R, double Dn, double Up, double invmu, bool accumulate) {
+  if (accumulate) {
+    a.L_dr[o] += R;
+    a.L_dn[o] += Dn;
+    a.L_up[o] += Up;
+    a.L_F[o] += R * invmu + 2 * (Up + Dn);
+    a.L_Id[o] += R + Dn;
+  } else {
+    __builtin_nontemporal_store(R, a.L_dr + o);
+    __builtin_nontemporal_store(Dn, a.L_dn + o);
+    __builtin_nontemporal_store(Up, a.L_up + o);
+    __builtin_nontemporal_store(R * invmu + 2 * (Up + Dn), a.L_F + o);
+    __builtin_nontemporal_store(R + Dn, a.L_Id + o);
+  }
+}
+
+template <int MAXT, bool PROF>
 __global__ __launch_bounds__(MAXT) void k_absorb_bandsum(EpiArgs a, int b0, int nbs, int accumulate) {
   // bands [b0, b0 + nbs) of every row (nbs <= blockDim.x <= 1024; spectra wider than 1024 bands take several launches, the
   // later ones adding to the outputs of the first)
@@ -64,10 +90,14 @@ __global__ __launch_bounds__(MAXT) void k_absorb_bandsum(EpiArgs a, int b0, int 
   const double* __restrict__ R = a.I_dr + cb;
   const double* __restrict__ D = a.I_df_d + cb;
   const double* __restrict__ U = a.I_df_u + cb;
-  // LDS: part[2][BS_CH][nwave][2][MAXG], ends[nwave][4][MAXG]
+  // LDS: part[2][BS_CH][nwave][NV][MAXG] (NV = 2 sums per level and group: A, D; PROF: + the level sums of I_dr, I_df_d, I_df_u),
+  // ends[nwave][4][MAXG], PROF: lev0[nwave][3][MAXG] (the level sums of row 0)
+  constexpr int NV = PROF ? 5 : 2;
   double* part = lds;
-  double* ends = lds + 2 * BS_CH * nwave * 2 * MAXG;
-  const int pstride = nwave * 2 * MAXG;  // doubles per level slot
+  double* ends = lds + 2 * BS_CH * nwave * NV * MAXG;
+  double* lev0 = ends + nwave * 4 * MAXG;
+  const int pstride = nwave * NV * MAXG;  // doubles per level slot
+  const double invmu = 1.0 / cos(psi);
 
   const bool act = tid < nbs;
   const int bi = act ? tid : 0;
@@ -82,6 +112,18 @@ __global__ __launch_bounds__(MAXT) void k_absorb_bandsum(EpiArgs a, int b0, int 
     }
   }
   double r0 = R[bi], d0 = D[bi], u0 = U[bi];
+  if constexpr (PROF) {  // level sums of row 0
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g)
+      if (g < ng) {
+        const double t0 = wave_sum_lane63(w[g] * r0), t1 = wave_sum_lane63(w[g] * d0), t2 = wave_sum_lane63(w[g] * u0);
+        if (lane == 63) {
+          lev0[(wave * 3 + 0) * MAXG + g] = t0;
+          lev0[(wave * 3 + 1) * MAXG + g] = t1;
+          lev0[(wave * 3 + 2) * MAXG + g] = t2;
+        }
+      }
+  }
   // energy-balance terms at the ground (diagnostics.py:476-530): transmitted I_d[0], soil-reflected I_df_u[0]
   if (a.totals) {
 #pragma unroll
@@ -103,8 +145,8 @@ __global__ __launch_bounds__(MAXT) void k_absorb_bandsum(EpiArgs a, int b0, int 
         const double* p = part + (buf * BS_CH + t) * pstride;
         double A = 0.0, Dg = 0.0;
         for (int wv = 0; wv < nwave; ++wv) {
-          A += p[(wv * 2 + 0) * MAXG + g];
-          Dg += p[(wv * 2 + 1) * MAXG + g];
+          A += p[(wv * NV + 0) * MAXG + g];
+          Dg += p[(wv * NV + 1) * MAXG + g];
         }
         const double dl = lai[k] - lai[k + 1];                      // model.py:248
         const double fsl = exp(-Kb * ((lai[k] + lai[k + 1]) / 2));  // :601-602
@@ -119,6 +161,16 @@ __global__ __launch_bounds__(MAXT) void k_absorb_bandsum(EpiArgs a, int b0, int 
           a.aI[o] = A;
           a.aI_sl[o] = adf * fsl + adr;                             // :631-633
           a.aI_sh[o] = adf * (1 - fsl);
+        }
+        if constexpr (PROF) {
+          if (accumulate) a.aI_dr[o] += adr; else a.aI_dr[o] = adr;
+          double sR = 0.0, sD = 0.0, sU = 0.0;
+          for (int wv = 0; wv < nwave; ++wv) {
+            sR += p[(wv * NV + 2) * MAXG + g];
+            sD += p[(wv * NV + 3) * MAXG + g];
+            sU += p[(wv * NV + 4) * MAXG + g];
+          }
+          store_level_profiles(a, ((long long)c * nz + k + 1) * ng + g, sR, sD, sU, invmu, accumulate != 0);  // level k + 1
         }
       }
     }
@@ -146,10 +198,18 @@ __global__ __launch_bounds__(MAXT) void k_absorb_bandsum(EpiArgs a, int b0, int 
         for (int g = 0; g < MAXG; ++g)
           if (g < ng) {
             const double ta = wave_sum_lane63(w[g] * av), td = wave_sum_lane63(wa[g] * r1[t]);
+            double* p = part + (buf * BS_CH + t) * pstride;
             if (lane == 63) {
-              double* p = part + (buf * BS_CH + t) * pstride;
-              p[(wave * 2 + 0) * MAXG + g] = ta;
-              p[(wave * 2 + 1) * MAXG + g] = td;
+              p[(wave * NV + 0) * MAXG + g] = ta;
+              p[(wave * NV + 1) * MAXG + g] = td;
+            }
+            if constexpr (PROF) {
+              const double s0 = wave_sum_lane63(w[g] * r1[t]), s1 = wave_sum_lane63(w[g] * d1[t]), s2 = wave_sum_lane63(w[g] * u1[t]);
+              if (lane == 63) {
+                p[(wave * NV + 2) * MAXG + g] = s0;
+                p[(wave * NV + 3) * MAXG + g] = s1;
+                p[(wave * NV + 4) * MAXG + g] = s2;
+              }
             }
           }
         r0 = r1[t];
@@ -174,14 +234,25 @@ __global__ __launch_bounds__(MAXT) void k_absorb_bandsum(EpiArgs a, int b0, int 
       }
   }
   if (prev_k0 >= 0) finish_chunk(prev_k0, prev_n, buf ^ 1);
-  if (a.totals) {
+  if (a.totals || PROF) {
     lds_barrier();
-    if (tid < ng * 4) {
+    if (a.totals && tid < ng * 4) {
       const int g = tid >> 2, q = tid & 3;
       double t = 0.0;
       for (int wv = 0; wv < nwave; ++wv) t += ends[(wv * 4 + q) * MAXG + g];
       double* o = a.totals + ((long long)c * ng + g) * 4 + q;
       *o = accumulate ? *o + t : t;
+    }
+    if constexpr (PROF) {
+      if (tid < ng) {  // level 0
+        double sR = 0.0, sD = 0.0, sU = 0.0;
+        for (int wv = 0; wv < nwave; ++wv) {
+          sR += lev0[(wv * 3 + 0) * MAXG + tid];
+          sD += lev0[(wv * 3 + 1) * MAXG + tid];
+          sU += lev0[(wv * 3 + 2) * MAXG + tid];
+        }
+        store_level_profiles(a, (long long)c * nz * ng + tid, sR, sD, sU, invmu, accumulate != 0);
+      }
     }
   }
 }
@@ -194,9 +265,9 @@ __device__ inline double column_kb(const EpiArgs& a, int c) {
   const double G = (kind == CRT_G_TABLE) ? a.g_at_psi[c] : G_closed(kind, a.g_param ? a.g_param[c] : 0.0, cos(psi), sin(psi));
   return G / cos(psi);
 }
-template <int NGT>
+template <int NGT, bool PROF = false>
 __device__ inline void bandsum_finish(const EpiArgs& a, int c, const double* raw, const double* ends, const double* __restrict__ lai, double Kb, int l,
-                                      int nlanes) {
+                                      int nlanes, const double* lev = nullptr) {
   const int ng = a.ngroup, nl = a.nz - 1;
   const long long ob = (long long)c * nl * ng;
   for (int i = l; i < nl * ng; i += nlanes) {
@@ -208,6 +279,16 @@ __device__ inline void bandsum_finish(const EpiArgs& a, int c, const double* raw
     __builtin_nontemporal_store(A, a.aI + ob + i);
     __builtin_nontemporal_store(adf * fsl + adr, a.aI_sl + ob + i);      // :631-633
     __builtin_nontemporal_store(adf * (1 - fsl), a.aI_sh + ob + i);
+    if constexpr (PROF) __builtin_nontemporal_store(adr, a.aI_dr + ob + i);
+  }
+  if constexpr (PROF) {  // band-integrated level profiles (diagnostics.py:81): lev = [nz][NGT][3] level sums of I_dr, I_df_d, I_df_u
+    const double invmu = 1.0 / cos(a.psi[c]);
+    const long long lb = (long long)c * a.nz * ng;
+    for (int i = l; i < a.nz * ng; i += nlanes) {
+      const int j = i / ng, g = i - j * ng;
+      const double* q = lev + (j * NGT + g) * 3;
+      store_level_profiles(a, lb + i, q[0], q[1], q[2], invmu, false);
+    }
   }
   if (a.totals && l < 4 * ng) {  // incoming, reflected, transmitted, soil-reflected
     const int g = l >> 2, q = l & 3;
@@ -222,7 +303,7 @@ __device__ inline void bandsum_finish(const EpiArgs& a, int c, const double* raw
 // crt_internal.hpp: 5 instructions per value instead of 18).  No barriers, no cross-wave traffic: the waves of a workgroup are
 // independent columns.  The raw band sums A_g(k), D_g(k) go to LDS; at the end the lanes turn them into the level outputs
 // (level factors f_sl(k), 1 - e^{-K_b dlai_k} evaluated there, lanes over levels) and write them coalesced.
-template <int NBT, int CH, int NGT, bool PF = false>
+template <int NBT, int CH, int NGT, bool PF = false, bool PROF = false>
 __global__ __launch_bounds__(256) void k_absorb_bandsum_w(EpiArgs a, int wpb, int per_wave) {
   extern __shared__ double lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -233,6 +314,7 @@ __global__ __launch_bounds__(256) void k_absorb_bandsum_w(EpiArgs a, int wpb, in
   const int nz = a.nz, nb = a.nb, ng = a.ngroup, nl = nz - 1;
   double* raw = lds + (size_t)wave * per_wave;  // [nl][NGT][2]: A_g(k), D_g(k)
   double* ends = raw + 2 * NGT * nl;            // [2][NGT][2]: ground (I_d, I_df_u), top (I_d, I_df_u)
+  double* lev = ends + 4 * NGT;                 // PROF: [nz][NGT][3] level sums of I_dr, I_df_d, I_df_u
   const long long cb = (long long)c * nz * nb;
   const double* __restrict__ R = a.I_dr + cb;
   const double* __restrict__ D = a.I_df_d + cb;
@@ -267,6 +349,20 @@ __global__ __launch_bounds__(256) void k_absorb_bandsum_w(EpiArgs a, int wpb, in
   };
   const double Kb = column_kb(a, c);  // now, not in the tail: three dependent round trips with nothing else of the wave in flight there
   if (a.totals) end_terms(ends);  // ground: transmitted I_d[0], soil-reflected I_df_u[0]  (diagnostics.py:476-530)
+  if constexpr (PROF) {  // level sums of row 0
+    double v[3 * NGT];
+#pragma unroll
+    for (int g = 0; g < NGT; ++g) {
+      v[3 * g] = v[3 * g + 1] = v[3 * g + 2] = 0.0;
+#pragma unroll
+      for (int i = 0; i < NBT; ++i) {
+        v[3 * g] += w[i][g] * r0[i];
+        v[3 * g + 1] += w[i][g] * d0[i];
+        v[3 * g + 2] += w[i][g] * u0[i];
+      }
+    }
+    wave_sum_store(v, lev, 3 * NGT, lane);
+  }
   // a chunk = CH levels: `fetch` issues its loads, `reduce` forms the level terms and the band sums
   auto fetch = [&](int k0, double (&r1)[CH][NBT], double (&d1)[CH][NBT], double (&u1)[CH][NBT]) {
     const int nlev = min(CH, nl - k0);
@@ -307,6 +403,28 @@ __global__ __launch_bounds__(256) void k_absorb_bandsum_w(EpiArgs a, int wpb, in
       }
     }
     wave_sum_store(v, raw + (size_t)k0 * NGT * 2, nlev * NGT * 2, lane);
+    if constexpr (PROF) {  // the level sums of rows k0 + 1 .. k0 + nlev
+      double v3[CH * NGT * 3];
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+#pragma unroll
+        for (int g = 0; g < NGT; ++g) {
+          double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+          if (t < nlev) {
+#pragma unroll
+            for (int i = 0; i < NBT; ++i) {
+              s0 += w[i][g] * r1[t][i];
+              s1 += w[i][g] * d1[t][i];
+              s2 += w[i][g] * u1[t][i];
+            }
+          }
+          v3[(t * NGT + g) * 3] = s0;
+          v3[(t * NGT + g) * 3 + 1] = s1;
+          v3[(t * NGT + g) * 3 + 2] = s2;
+        }
+      }
+      wave_sum_store(v3, lev + (size_t)(k0 + 1) * NGT * 3, nlev * NGT * 3, lane);
+    }
   };
   if constexpr (PF) {
     // narrow spectra (one band per lane): a chunk is only CH rows of nb * 8 bytes per array, too little in flight to cover the
@@ -330,7 +448,7 @@ __global__ __launch_bounds__(256) void k_absorb_bandsum_w(EpiArgs a, int wpb, in
   }
   if (a.totals) end_terms(ends + 2 * NGT);  // canopy top: incoming I_d[top], reflected I_df_u[top]
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave: LDS operations complete in order; make the sums visible to all lanes
-  bandsum_finish<NGT>(a, c, raw, ends, a.lai + (long long)c * nz, Kb, lane, 64);
+  bandsum_finish<NGT, PROF>(a, c, raw, ends, a.lai + (long long)c * nz, Kb, lane, 64, lev);
 }
 
 // k_absorb_bandsum_l: narrow spectra (32 < nb <= 48, even; nz <= 257): one wave per column, the lanes over LAYERS.
@@ -768,6 +886,26 @@ __global__ __launch_bounds__(256) void k_absorb_tile(AbsArgs a, int T) {
 
 // ------------------------------------------------------------------------------------------
 // bandwidth probes: plain 16-B-per-lane streaming fill / copy, grid-stride
+// out[row][g] = sum_b w[g][b] X[row][b]: diagnostics.band's reduction (diagnostics.py:81) for ANY variable with a trailing wavelength
+// axis -- one wave per row, lanes over bands, four group totals per set of lane exchanges (wave_sum4)
+__global__ __launch_bounds__(256) void k_band_reduce(const double* __restrict__ X, long long nrow, int nb, const double* __restrict__ w, int ng,
+                                                     double* __restrict__ out) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= nrow) return;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const double* x = X + row * nb;
+  for (int b = lane; b < nb; b += 64) {
+    const double v = x[b];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (g < ng) acc[g] += w[(long long)g * nb + b] * v;
+  }
+  const double z = wave_sum4(acc[0], acc[1], acc[2], acc[3]);
+  const int g = wave_sum4_slot(lane >> 4);
+  if ((lane & 15) == 0 && g < ng) out[row * ng + g] = z;
+}
+
 __global__ __launch_bounds__(256) void k_probe_math(const double* x, size_t n, double* e, double* sn, double* cs) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -988,10 +1126,15 @@ CRT_ENTRY32(crt_hip_bf_f32, CRT_SCHEME_BF)
 CRT_ENTRY32(crt_hip_zq_pa_f32, CRT_SCHEME_ZQ_PA)
 #undef CRT_ENTRY32
 
-int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, const double* I_dr, const double* I_df_d,
-                               const double* I_df_u, const double* band_w, int32_t ngroup, double* aI, double* aI_sl,
-                               double* aI_sh, double* totals, crt_stream_t stream) {
-  if (!cols || !bands || !I_dr || !I_df_d || !I_df_u || !band_w || !aI || !aI_sl || !aI_sh) return CRT_ERR_BAD_ARG;
+int crt_hip_absorb_bandsum2_f64(const crt_columns* cols, const crt_bands* bands, const double* I_dr, const double* I_df_d,
+                                const double* I_df_u, const double* band_w, int32_t ngroup, const crt_bandsum_out* out, crt_stream_t stream) {
+  if (!cols || !bands || !I_dr || !I_df_d || !I_df_u || !band_w || !out || !out->aI || !out->aI_sl || !out->aI_sh) return CRT_ERR_BAD_ARG;
+  double *aI = out->aI, *aI_sl = out->aI_sl, *aI_sh = out->aI_sh, *totals = out->totals;
+  // the optional outputs come all together or not at all: the direct-beam part of the absorption + the five level profiles
+  const int nopt = (out->aI_dr != nullptr) + (out->I_dr != nullptr) + (out->I_df_d != nullptr) + (out->I_df_u != nullptr) + (out->F != nullptr) +
+                   (out->I_d != nullptr);
+  if (nopt != 0 && nopt != 6) return CRT_ERR_BAD_ARG;
+  const bool prof = nopt == 6;
   if (cols->ncol <= 0 || cols->nz < 2 || bands->nb <= 0 || ngroup <= 0 || ngroup > MAXG) return CRT_ERR_BAD_ARG;
   if (!cols->psi || !cols->lai || !cols->g_kind || !bands->leaf_r || !bands->leaf_t) return CRT_ERR_BAD_ARG;
   EpiArgs a;
@@ -1015,12 +1158,19 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
   a.aI_sl = aI_sl;
   a.aI_sh = aI_sh;
   a.totals = totals;
+  a.aI_dr = out->aI_dr;
+  a.L_dr = out->I_dr;
+  a.L_dn = out->I_df_d;
+  a.L_up = out->I_df_u;
+  a.L_F = out->F;
+  a.L_Id = out->I_d;
   // measured (tools/epilogue_bench.py): nb = 20: 1.15 ms per wave-column vs 0.85 ms per half-wave-column; nb = 38: 1.11 vs 1.26 (the second band
   // slot of a half is nearly empty and doubles the per-band work) -> halves only up to 32 bands
   const bool aligned16 = ((reinterpret_cast<uintptr_t>(I_dr) | reinterpret_cast<uintptr_t>(I_df_d) | reinterpret_cast<uintptr_t>(I_df_u)) & 15) == 0;
   // measured (tools/bandsum_shapes.py, 9.1 GB of profiles): lanes over layers vs lanes over bands (one band per lane, next chunk prefetched):
   //   1e5 x 34 x 100: 1.69 vs 1.83 ms;  1e5 x 38 x 100: 1.89 vs 2.09;  1e5 x 48 x 80: 1.85 vs 1.88;  1e5 x 64 x 60: 2.02 vs 1.66 -> up to 48 bands
-  if (a.nb > 32 && a.nb <= 48 && a.nb % 2 == 0 && aligned16 && a.nz <= 257 && (long long)a.nz * a.nb < (1ll << 31)) {  // lanes over layers
+  // (with the level profiles requested the band-lane kernels below serve every width: they hold each level's values in registers anyway)
+  if (!prof && a.nb > 32 && a.nb <= 48 && a.nb % 2 == 0 && aligned16 && a.nz <= 257 && (long long)a.nz * a.nb < (1ll << 31)) {  // lanes over layers
     const int nl = a.nz - 1;
     const int ngt = a.ngroup == 1 ? 1 : a.ngroup <= 3 ? 3 : 4;
     const int nbp = (a.nb % 4 == 2) ? a.nb : a.nb + 2;
@@ -1034,7 +1184,7 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
       return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
     }
   }
-  if (a.nb <= 32 && (long long)a.nz * a.nb < (1ll << 31)) {  // a column per half wave
+  if (!prof && a.nb <= 32 && (long long)a.nz * a.nb < (1ll << 31)) {  // a column per half wave
     const int nl = a.nz - 1;
     const int ngt = a.ngroup == 1 ? 1 : a.ngroup <= 3 ? 3 : 4;
     const int per_col = 2 * ngt * nl + 4 * ngt;
@@ -1058,7 +1208,7 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
   if (a.nb <= 512 && (long long)a.nz * a.nb < (1ll << 31)) {  // one wave per column
     const int nl = a.nz - 1;
     const int ngt = a.ngroup == 1 ? 1 : a.ngroup <= 3 ? 3 : 4;
-    const int per_wave = 2 * ngt * nl + 4 * ngt;
+    const int per_wave = 2 * ngt * nl + 4 * ngt + (prof ? 3 * ngt * a.nz : 0);
     int wpb = 4;
     while (wpb > 1 && (size_t)wpb * per_wave * sizeof(double) > 60 * 1024) wpb >>= 1;
     const size_t shw = (size_t)wpb * per_wave * sizeof(double);
@@ -1066,6 +1216,24 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
       const int nbt = (a.nb + 63) / 64;
       const dim3 grid((a.ncol + wpb - 1) / wpb), block(64 * wpb);
       hipStream_t sw = static_cast<hipStream_t>(stream);
+      auto launch_p = [&](auto ngt) {  // with the level profiles (chunks of two levels: the extra sums live in registers too)
+        constexpr int NGT = decltype(ngt)::value;
+        switch (nbt) {
+          case 1: hipLaunchKernelGGL((k_absorb_bandsum_w<1, 2, NGT, false, true>), grid, block, shw, sw, a, wpb, per_wave); break;
+          case 2: hipLaunchKernelGGL((k_absorb_bandsum_w<2, 2, NGT, false, true>), grid, block, shw, sw, a, wpb, per_wave); break;
+          case 3: hipLaunchKernelGGL((k_absorb_bandsum_w<3, 2, NGT, false, true>), grid, block, shw, sw, a, wpb, per_wave); break;
+          case 4: hipLaunchKernelGGL((k_absorb_bandsum_w<4, 2, NGT, false, true>), grid, block, shw, sw, a, wpb, per_wave); break;
+          case 5: hipLaunchKernelGGL((k_absorb_bandsum_w<5, 2, NGT, false, true>), grid, block, shw, sw, a, wpb, per_wave); break;
+          case 6: hipLaunchKernelGGL((k_absorb_bandsum_w<6, 1, NGT, false, true>), grid, block, shw, sw, a, wpb, per_wave); break;
+          default: hipLaunchKernelGGL((k_absorb_bandsum_w<8, 1, NGT, false, true>), grid, block, shw, sw, a, wpb, per_wave); break;
+        }
+      };
+      if (prof) {
+        if (a.ngroup == 1) launch_p(std::integral_constant<int, 1>{});
+        else if (a.ngroup <= 3) launch_p(std::integral_constant<int, 3>{});
+        else launch_p(std::integral_constant<int, 4>{});
+        return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+      }
       auto launch = [&](auto ngt) {
         constexpr int NGT = decltype(ngt)::value;
         switch (nbt) {
@@ -1088,28 +1256,74 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
   for (int b0 = 0; b0 < a.nb; b0 += 1024) {  // one launch per 1024 bands (the usual case: one)
     const int nbs = std::min(1024, a.nb - b0);
     const int nthr = ((nbs + 63) / 64) * 64;
-    const size_t sh = ((size_t)2 * BS_CH * (nthr / 64) * 2 * MAXG + (size_t)(nthr / 64) * 4 * MAXG) * sizeof(double);
-    if (nthr <= 256) hipLaunchKernelGGL((k_absorb_bandsum<256>), dim3(a.ncol), dim3(nthr), sh, s, a, b0, nbs, b0 > 0);
-    else if (nthr <= 512) hipLaunchKernelGGL((k_absorb_bandsum<512>), dim3(a.ncol), dim3(nthr), sh, s, a, b0, nbs, b0 > 0);
-    else hipLaunchKernelGGL((k_absorb_bandsum<1024>), dim3(a.ncol), dim3(nthr), sh, s, a, b0, nbs, b0 > 0);
+    const size_t sh = ((size_t)2 * BS_CH * (nthr / 64) * (prof ? 5 : 2) * MAXG + (size_t)(nthr / 64) * (4 + (prof ? 3 : 0)) * MAXG) * sizeof(double);
+    if (prof) {
+      if (nthr <= 256) hipLaunchKernelGGL((k_absorb_bandsum<256, true>), dim3(a.ncol), dim3(nthr), sh, s, a, b0, nbs, b0 > 0);
+      else if (nthr <= 512) hipLaunchKernelGGL((k_absorb_bandsum<512, true>), dim3(a.ncol), dim3(nthr), sh, s, a, b0, nbs, b0 > 0);
+      else hipLaunchKernelGGL((k_absorb_bandsum<1024, true>), dim3(a.ncol), dim3(nthr), sh, s, a, b0, nbs, b0 > 0);
+    } else {
+      if (nthr <= 256) hipLaunchKernelGGL((k_absorb_bandsum<256, false>), dim3(a.ncol), dim3(nthr), sh, s, a, b0, nbs, b0 > 0);
+      else if (nthr <= 512) hipLaunchKernelGGL((k_absorb_bandsum<512, false>), dim3(a.ncol), dim3(nthr), sh, s, a, b0, nbs, b0 > 0);
+      else hipLaunchKernelGGL((k_absorb_bandsum<1024, false>), dim3(a.ncol), dim3(nthr), sh, s, a, b0, nbs, b0 > 0);
+    }
   }
   return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+}
+
+int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, const double* I_dr, const double* I_df_d,
+                               const double* I_df_u, const double* band_w, int32_t ngroup, double* aI, double* aI_sl,
+                               double* aI_sh, double* totals, crt_stream_t stream) {
+  crt_bandsum_out o = {};
+  o.aI = aI;
+  o.aI_sl = aI_sl;
+  o.aI_sh = aI_sh;
+  o.totals = totals;
+  return crt_hip_absorb_bandsum2_f64(cols, bands, I_dr, I_df_d, I_df_u, band_w, ngroup, &o, stream);
+}
+
+int crt_hip_integrated2_f64(int scheme, const crt_columns* cols, const crt_bands* bands, const crt_options* opts,
+                            const double* band_w, int32_t ngroup, const crt_bandsum_out* out, void* workspace, size_t workspace_bytes,
+                            crt_stream_t stream) {
+  if (!band_w || !out || !out->aI || !out->aI_sl || !out->aI_sh || ngroup <= 0 || ngroup > INT_MAXG || !cols) return CRT_ERR_BAD_ARG;
+  const int nopt = (out->aI_dr != nullptr) + (out->I_dr != nullptr) + (out->I_df_d != nullptr) + (out->I_df_u != nullptr) + (out->F != nullptr) +
+                   (out->I_d != nullptr);
+  if (nopt != 0 && nopt != 6) return CRT_ERR_BAD_ARG;
+  IntArgs ia;
+  ia.lai = cols->lai;
+  ia.band_w = band_w;
+  ia.ngroup = ngroup;
+  ia.aI = out->aI;
+  ia.aI_sl = out->aI_sl;
+  ia.aI_sh = out->aI_sh;
+  ia.totals = out->totals;
+  ia.aI_dr = out->aI_dr;
+  ia.L_dr = out->I_dr;
+  ia.L_dn = out->I_df_d;
+  ia.L_up = out->I_df_u;
+  ia.L_F = out->F;
+  ia.L_Id = out->I_d;
+  crt_outputs none = {};
+  return solve_impl(scheme, cols, bands, opts, &none, workspace, workspace_bytes, stream, 0, &ia);
 }
 
 int crt_hip_integrated_f64(int scheme, const crt_columns* cols, const crt_bands* bands, const crt_options* opts,
                            const double* band_w, int32_t ngroup, double* aI, double* aI_sl, double* aI_sh, double* totals,
                            void* workspace, size_t workspace_bytes, crt_stream_t stream) {
-  if (!band_w || !aI || !aI_sl || !aI_sh || ngroup <= 0 || ngroup > INT_MAXG || !cols) return CRT_ERR_BAD_ARG;
-  IntArgs ia;
-  ia.lai = cols->lai;
-  ia.band_w = band_w;
-  ia.ngroup = ngroup;
-  ia.aI = aI;
-  ia.aI_sl = aI_sl;
-  ia.aI_sh = aI_sh;
-  ia.totals = totals;
-  crt_outputs none = {};
-  return solve_impl(scheme, cols, bands, opts, &none, workspace, workspace_bytes, stream, 0, &ia);
+  crt_bandsum_out o = {};
+  o.aI = aI;
+  o.aI_sl = aI_sl;
+  o.aI_sh = aI_sh;
+  o.totals = totals;
+  return crt_hip_integrated2_f64(scheme, cols, bands, opts, band_w, ngroup, &o, workspace, workspace_bytes, stream);
+}
+
+int crt_hip_band_reduce_f64(const double* X, int64_t nrow, int32_t nb, const double* band_w, int32_t ngroup, double* out, crt_stream_t stream) {
+  if (!X || !band_w || !out || nrow < 0 || nb <= 0 || ngroup <= 0 || ngroup > 4) return CRT_ERR_BAD_ARG;
+  if (nrow == 0) return CRT_OK;
+  const long long nblk = (nrow + 3) / 4;
+  if (nblk > 0x7fffffffLL) return CRT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_band_reduce, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), X, (long long)nrow, nb, band_w, ngroup, out);
+  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
 }
 
 int crt_hip_absorb_f64(const crt_columns* cols, const crt_bands* bands, const double* I_dr, const double* I_df_d,

@@ -317,6 +317,14 @@ struct IntArgs {
   double* aI_sl;
   double* aI_sh;
   double* totals;        // [ncol][ngroup][4]: incoming, reflected, transmitted, soil-reflected (may be NULL)
+  // optional, all or none (crt_bandsum_out): direct-beam part of the absorption [ncol][nz-1][ngroup] and the band-integrated level
+  // profiles [ncol][nz][ngroup] of I_dr, I_df_d, I_df_u, F, I_d (diagnostics.py:84-91)
+  double* aI_dr;
+  double* L_dr;
+  double* L_dn;
+  double* L_up;
+  double* L_F;
+  double* L_Id;
 };
 
 // Sum over each 16-lane DPP row, result in every lane of the row: 4 steps of (2 x v_mov_b32 dpp + v_add_f64), pure VALU
@@ -408,12 +416,34 @@ struct IntLds {
   double* part;
   double* ends;
   double* pdr;
+  double* lev;   // PROF: [nz][nwave][2][INT_MAXG] wave sums of w I_df_d, w I_df_u per level
+  double* pi0;   // PROF: [nwave][INT_MAXG] wave sums of w I_dr0 (I_dr factorises into band x level)
 };
+// carve the integrated kernels' LDS area (after the record) into its parts
+__device__ inline IntLds int_lds_carve(double* base, int nz, int nwave, bool prof) {
+  IntLds L;
+  L.part = base;
+  L.ends = L.part + (size_t)nz * nwave * INT_MAXG;
+  L.pdr = L.ends + (size_t)2 * nwave * 2 * INT_MAXG;
+  L.lev = L.pdr + (size_t)nwave * INT_MAXG;
+  L.pi0 = L.lev + (prof ? (size_t)nz * nwave * 2 * INT_MAXG : 0);
+  return L;
+}
 
-template <bool ROWS>
+template <bool ROWS, bool PROF = false>
 __device__ inline void int_accumulate(const IntLds& L, int nwave, int wave, int lane, int nz, int j, int ng, const double (&w)[INT_MAXG],
                                       bool active, double idr, double dn, double up) {
   if constexpr (!ROWS) {
+    if constexpr (PROF) {  // the level sums of the two diffuse streams (the direct beam's follow from one sum per column)
+      const int g2 = wave_sum4_slot(lane >> 4);
+      const double dd = active ? dn : 0.0, uu = active ? up : 0.0;
+      const double zd = wave_sum4(w[0] * dd, w[1] * dd, w[2] * dd, w[3] * dd);
+      const double zu = wave_sum4(w[0] * uu, w[1] * uu, w[2] * uu, w[3] * uu);
+      if ((lane & 15) == 0 && g2 < ng) {
+        L.lev[((j * nwave + wave) * 2 + 0) * INT_MAXG + g2] = zd;
+        L.lev[((j * nwave + wave) * 2 + 1) * INT_MAXG + g2] = zu;
+      }
+    }
     // wave totals of all (up to four) band groups with ONE wave_sum4: 21 VALU instructions per level instead of 18 per group
     // (w[g] = 0 for g >= ngroup and for inactive lanes)
     const int g = wave_sum4_slot(lane >> 4);
@@ -460,9 +490,28 @@ __device__ inline void int_accumulate(const IntLds& L, int nwave, int wave, int 
 }
 
 // after the sweep (call with all threads of the workgroup): combine the partials and write the column's outputs
-template <bool ROWS>
-__device__ inline void int_finish(const IntLds& L, const IntArgs& ia, int nwave, int nz, int c, double Kb) {
+template <bool ROWS, bool PROF = false>
+__device__ inline void int_finish(const IntLds& L, const IntArgs& ia, int nwave, int nz, int c, double Kb, double invmu = 0.0) {
   __syncthreads();
+  if constexpr (PROF) {
+    const int ngp = ia.ngroup;
+    for (int i = threadIdx.x; i < nz * ngp; i += blockDim.x) {
+      const int j = i / ngp, g = i - j * ngp;
+      double p0 = 0.0, sD = 0.0, sU = 0.0;
+      for (int wv = 0; wv < nwave; ++wv) {
+        p0 += L.pi0[wv * INT_MAXG + g];
+        sD += L.lev[((j * nwave + wv) * 2 + 0) * INT_MAXG + g];
+        sU += L.lev[((j * nwave + wv) * 2 + 1) * INT_MAXG + g];
+      }
+      const double sR = exp(-Kb * ia.lai[(long long)c * nz + j]) * p0;  // sum_b w I_dr0[b] e^{-K_b lai_j}
+      const long long o = ((long long)c * nz + j) * ngp + g;
+      ia.L_dr[o] = sR;
+      ia.L_dn[o] = sD;
+      ia.L_up[o] = sU;
+      ia.L_F[o] = sR * invmu + 2 * (sU + sD);
+      ia.L_Id[o] = sR + sD;
+    }
+  }
   const int ng = ia.ngroup, nrow = ROWS ? nwave * 4 : nwave;
   const double* lai = ia.lai + (long long)c * nz;
   for (int i = threadIdx.x; i < (nz - 1) * ng; i += blockDim.x) {
@@ -482,6 +531,7 @@ __device__ inline void int_finish(const IntLds& L, const IntArgs& ia, int nwave,
     ia.aI[o] = a;
     ia.aI_sl[o] = adf * fsl + adr;
     ia.aI_sh[o] = adf * (1 - fsl);
+    if constexpr (PROF) ia.aI_dr[o] = adr;
   }
   if (ia.totals) {
     for (int i = threadIdx.x; i < ng * 4; i += blockDim.x) {
@@ -494,9 +544,10 @@ __device__ inline void int_finish(const IntLds& L, const IntArgs& ia, int nwave,
   }
 }
 
-__host__ __device__ inline size_t int_lds_doubles(int nz, int nwave, bool rows = false) {
+__host__ __device__ inline size_t int_lds_doubles(int nz, int nwave, bool rows = false, bool prof = false) {
   const size_t nslot = rows ? (size_t)nwave * 4 : (size_t)nwave;
-  return (size_t)nz * nslot * INT_MAXG + 2 * nslot * 2 * INT_MAXG + (size_t)nwave * INT_MAXG;
+  return (size_t)nz * nslot * INT_MAXG + 2 * nslot * 2 * INT_MAXG + (size_t)nwave * INT_MAXG +
+         (prof ? (size_t)nz * nwave * 2 * INT_MAXG + (size_t)nwave * INT_MAXG : 0);
 }
 
 int launch_closed_int(int scheme, const SolveArgs& a, const IntArgs& ia, hipStream_t s);

@@ -998,7 +998,7 @@ int launch_io(const SolveArgs& a, hipStream_t s, int force) {
 // ------------------------------------------------------------------------------------------
 // k_int: integrated outputs only (see IntArgs in crt_internal.hpp).  One workgroup per column, one lane per band; the
 // level values never leave the registers, the only cross-lane traffic is ngroup shuffle reductions per level.
-template <class S, typename TIO, int MAXT, bool ROWS>
+template <class S, typename TIO, int MAXT, bool PROF>
 __global__ __launch_bounds__(MAXT) void k_int(SolveArgs a, IntArgs ia, int rec_dbl) {
   extern __shared__ double lds[];
   const int nb = a.nb, nz = a.nz, ng = ia.ngroup;
@@ -1010,10 +1010,7 @@ __global__ __launch_bounds__(MAXT) void k_int(SolveArgs a, IntArgs ia, int rec_d
   }
   __syncthreads();
   const double* rec = lds;
-  IntLds L;
-  L.part = lds + rec_dbl;
-  L.ends = L.part + (size_t)nz * (ROWS ? nwave * 4 : nwave) * INT_MAXG;
-  L.pdr = L.ends + (size_t)2 * (ROWS ? nwave * 4 : nwave) * 2 * INT_MAXG;
+  const IntLds L = int_lds_carve(lds + rec_dbl, nz, nwave, PROF);
   const bool active = tid < nb;
   const int b = active ? tid : 0;
   const BandIn in = load_band<TIO>(a, c, b, S::SOIL);
@@ -1027,13 +1024,17 @@ __global__ __launch_bounds__(MAXT) void k_int(SolveArgs a, IntArgs ia, int rec_d
     if (g < ng) {
       const double t = wave_sum_all(w[g] * (1 - (in.r + in.t)) * in.I_dr0);
       if (lane == 0) L.pdr[wave * INT_MAXG + g] = t;
+      if constexpr (PROF) {
+        const double t0 = wave_sum_all(w[g] * in.I_dr0);
+        if (lane == 0) L.pi0[wave * INT_MAXG + g] = t0;
+      }
     }
   for (int j = 0; j < nz; ++j) {
     double val[S::NARR];
     st.level(j, rec, nz, val);  // val[0..2] = I_dr, I_df_d, I_df_u for every scheme
-    int_accumulate<ROWS>(L, nwave, wave, lane, nz, j, ng, w, active, val[0], val[1], val[2]);
+    int_accumulate<false, PROF>(L, nwave, wave, lane, nz, j, ng, w, active, val[0], val[1], val[2]);
   }
-  int_finish<ROWS>(L, ia, nwave, nz, c, rec[S_KB]);
+  int_finish<false, PROF>(L, ia, nwave, nz, c, rec[S_KB], rec[S_INVMU]);
 }
 
 template <class S, typename TIO>
@@ -1041,22 +1042,20 @@ int launch_int(const SolveArgs& a, const IntArgs& ia, hipStream_t s) {
   if (a.nb > 1024) return CRT_ERR_UNSUPPORTED;
   const int nthr = ((a.nb + 63) / 64) * 64;
   const int rec_dbl = (a.reclen + 1) & ~1;
-  // per-row partials (4 DPP steps per value) while they leave three workgroups per CU, else per-wave totals (6 steps):
-  // measured 2s 1e4x300x60: rows 0.625 ms, wave totals 0.80 ms, __shfl_xor butterflies 1.59 ms
-  // (round 1: per-row partials, 4 DPP steps per value, while they left three workgroups per CU; round 2: wave totals of all band
-  //  groups with one wave_sum4 -- fewer instructions AND a quarter of the LDS, so always)
-  const bool rows = false;
-  const size_t sh = (rec_dbl + int_lds_doubles(a.nz, nthr / 64, rows)) * sizeof(double);
+  // wave totals of all band groups with one wave_sum4 per level (round 2; per-row partials and __shfl_xor butterflies before that:
+  // 2s 1e4 x 300 x 60 0.80 / 0.625 / 1.59 ms)
+  const bool prof = ia.L_dr != nullptr;
+  const size_t sh = (rec_dbl + int_lds_doubles(a.nz, nthr / 64, false, prof)) * sizeof(double);
   if (sh > 160 * 1024) return CRT_ERR_UNSUPPORTED;
   auto go = [&](auto kern) {
     if (sh > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, ia, rec_dbl);
-    note_kernel("k_int<%s>%s", S::NAME, rows ? " row partials" : " wave totals");
+    note_kernel("k_int<%s>%s", S::NAME, prof ? " + level profiles" : " wave totals");
     return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
   };
-  if (rows) {
+  if (prof) {
     if (nthr <= 256) return go(k_int<S, TIO, 256, true>);
     if (nthr <= 512) return go(k_int<S, TIO, 512, true>);
     return go(k_int<S, TIO, 1024, true>);

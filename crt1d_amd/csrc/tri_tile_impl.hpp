@@ -375,17 +375,14 @@ int launch_mt(const SolveArgs& a, hipStream_t s, int nthr) {
 // ------------------------------------------------------------------------------------------
 // Integrated outputs only (IntArgs, crt_internal.hpp): the same checkpointed sweep, but instead of staging and flushing
 // profiles every level's net flux is reduced across the bands with ngroup wave shuffles.
-template <class S, typename TIO, int M>
+template <class S, typename TIO, int M, bool PROF>
 __device__ __forceinline__ void tri_int_body(const SolveArgs& a, const IntArgs& ia, int off_ck, int off_int, double* lds) {
   const int nb = a.nb, nz = a.nz, ng = ia.ngroup;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
   const int c = blockIdx.x;
   const double* rec = lds;
   double* ck = lds + off_ck + tid;  // [nck][2][nthr]
-  IntLds L;
-  L.part = lds + off_int;
-  L.ends = L.part + (size_t)nz * nwave * INT_MAXG;
-  L.pdr = L.ends + (size_t)2 * nwave * 2 * INT_MAXG;
+  const IntLds L = int_lds_carve(lds + off_int, nz, nwave, PROF);
   const bool active = tid < nb;
   const int b = active ? tid : 0;
   S st;
@@ -401,6 +398,10 @@ __device__ __forceinline__ void tri_int_body(const SolveArgs& a, const IntArgs& 
     if (g < ng) {
       const double t = wave_sum_all(w[g] * leaf_a * bc);
       if (lane == 0) L.pdr[wave * INT_MAXG + g] = t;
+      if constexpr (PROF) {
+        const double t0 = wave_sum_all(w[g] * bc);
+        if (lane == 0) L.pi0[wave * INT_MAXG + g] = t0;
+      }
     }
   const int K = S::rows(nz);
   double e, f;
@@ -436,14 +437,14 @@ __device__ __forceinline__ void tri_int_body(const SolveArgs& a, const IntArgs& 
           st.top(rec, nz, be[i], bf[i], o);
         else
           st.back(k, rec, nz, be[i], bf[i], o);
-        if (k < nz) int_accumulate<false>(L, nwave, wave, lane, nz, k, ng, w, active, bc * rec[REC_HDR + k], o[0], o[1]);
+        if (k < nz) int_accumulate<false, PROF>(L, nwave, wave, lane, nz, k, ng, w, active, bc * rec[REC_HDR + k], o[0], o[1]);
       }
     }
   }
-  int_finish<false>(L, ia, nwave, nz, c, rec[S_KB]);
+  int_finish<false, PROF>(L, ia, nwave, nz, c, rec[S_KB], rec[S_INVMU]);
 }
 
-template <class S, typename TIO, int M, int MAXT>
+template <class S, typename TIO, int M, int MAXT, bool PROF>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(M <= 8 ? 5 : 3))) void k_tri_int(SolveArgs a, IntArgs ia, int off_ck, int off_int) {
   extern __shared__ double lds[];
   {
@@ -454,11 +455,11 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(M <= 8 ? 5
   typedef typename UniformOf<S>::type SU;
   if constexpr (!std::is_same<S, SU>::value) {
     if (lds[S_UNIF] != 0.0) {
-      tri_int_body<SU, TIO, M>(a, ia, off_ck, off_int, lds);
+      tri_int_body<SU, TIO, M, PROF>(a, ia, off_ck, off_int, lds);
       return;
     }
   }
-  tri_int_body<S, TIO, M>(a, ia, off_ck, off_int, lds);
+  tri_int_body<S, TIO, M, PROF>(a, ia, off_ck, off_int, lds);
 }
 
 template <class S, typename TIO, int M>
@@ -467,19 +468,25 @@ int launch_int_m(const SolveArgs& a, const IntArgs& ia, hipStream_t s, int nthr)
   const int nck = (K - 1) / M + 1;
   const int off_ck = (a.reclen + 1) & ~1;
   const int off_int = off_ck + 2 * nck * nthr;
-  const size_t sh = ((size_t)off_int + int_lds_doubles(a.nz, nthr / 64)) * sizeof(double);
+  const bool prof = ia.L_dr != nullptr;
+  const size_t sh = ((size_t)off_int + int_lds_doubles(a.nz, nthr / 64, false, prof)) * sizeof(double);
   if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
   auto go = [&](auto kern) {
     if (sh > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, ia, off_ck, off_int);
-    note_kernel("k_tri_int<%s> M=%d", S::NAME, M);
+    note_kernel("k_tri_int<%s> M=%d%s", S::NAME, M, prof ? " + level profiles" : "");
     return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
   };
-  if (nthr <= 256) return go(k_tri_int<S, TIO, M, 256>);
-  if (nthr <= 512) return go(k_tri_int<S, TIO, M, 512>);
-  return go(k_tri_int<S, TIO, M, 1024>);
+  if (prof) {
+    if (nthr <= 256) return go(k_tri_int<S, TIO, M, 256, true>);
+    if (nthr <= 512) return go(k_tri_int<S, TIO, M, 512, true>);
+    return go(k_tri_int<S, TIO, M, 1024, true>);
+  }
+  if (nthr <= 256) return go(k_tri_int<S, TIO, M, 256, false>);
+  if (nthr <= 512) return go(k_tri_int<S, TIO, M, 512, false>);
+  return go(k_tri_int<S, TIO, M, 1024, false>);
 }
 
 template <class S, typename TIO>

@@ -29,11 +29,34 @@ def x_frac_in_bounds(xe, bounds):
     return w
 
 
-def band_weights(wle, names=("PAR", "NIR", "solar")):
-    """Stack of weight vectors ``(len(names), n_wl)`` for the device band-sum epilogue."""
+# CODATA 2018 exact SI values (what scipy.constants holds; crt1d/spectra.py:10-13 imports them from there)
+_H_PLANCK = 6.62607015e-34  # J s
+_C_LIGHT = 299792458.0  # m s-1
+_N_AVOGADRO = 6.02214076e23  # mol-1
+
+
+def e_wl_umol(wl_um):
+    """J per micromole of photons at wavelength ``wl_um`` (micrometres); ``crt1d/spectra.py:30-39`` (same operation order)."""
+    wl = np.asarray(wl_um, dtype=float) * 1e-6
+    e_wl_1 = _H_PLANCK * _C_LIGHT / wl
+    e_wl_mol = e_wl_1 * _N_AVOGADRO
+    return e_wl_mol * 1e-6
+
+
+def band_weights(wle, names=("PAR", "NIR", "solar"), *, wl=None, pfd=False):
+    """Stack of weight vectors ``(len(names), n_wl)`` for the device band-sum epilogue: ``_x_frac_in_bounds`` of each named band
+    (``diagnostics.py:71``).  ``pfd=True``: the photon-flux-density variants of ``diagnostics.band(..., calc_PFD=True)``
+    (``:92-104``; ``_E_to_PFD_da`` ``:19-36`` multiplies every band by ``1 / e_wl_umol(wl)`` BEFORE the band sum, because photon energy
+    depends on wavelength) -- the same sums with the weights divided by ``e_wl_umol(wl)``; ``wl`` = band centres (micrometres), by
+    default the mid-points of ``wle``.  W m-2 in, micromol photons m-2 s-1 out."""
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return np.stack([x_frac_in_bounds(wle, BAND_DEFNS_UM[n]) for n in names])
+        w = np.stack([x_frac_in_bounds(wle, BAND_DEFNS_UM[n]) for n in names])
+    if pfd:
+        wle = np.asarray(wle, dtype=float)
+        wl = 0.5 * (wle[:-1] + wle[1:]) if wl is None else np.asarray(wl, dtype=float)
+        w = w * (1.0 / e_wl_umol(wl))[None, :]
+    return w
 
 
 def edges_from_centers_widths(wl, dwl):

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 2
+#define CRT_ABI_VERSION 3
 
 /* leaf-angle G(psi) kinds: crt1d/leaf_angle.py:118-202 */
 enum crt_g_kind {
@@ -204,6 +204,35 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
                                double* aI_sh, double* totals, crt_stream_t stream);
 
 /*
+ * The complete output of diagnostics.band (crt1d/diagnostics.py:39-108) for up to four band groups at once: besides the layer
+ * absorption sums above, the band-integrated LEVEL profiles of every irradiance variable band() reduces (:84-91; the variables of
+ * Model.to_xr, model.py:421-426): I_dr, I_df_d, I_df_u, F and I_d = I_dr + I_df_d, each [ncol][nz][ngroup]
+ *     X_g(z) = sum_b band_w[g][b] X(z, b)                                            (diagnostics.py:81)
+ * and aI_dr [ncol][nz-1][ngroup], the direct-beam part of the absorbed irradiance, from which the remaining entries of the
+ * reference's absorption dict follow exactly: aI_df = aI - aI_dr, aI_df_sl = aI_sl - aI_dr, aI_df_sh = aI_sh (model.py:628-634).
+ * calc_PFD=True (:92-104, _E_to_PFD_da :19-36) is a choice of WEIGHTS: band_w[g][b] / e_wl_umol(wl[b]) gives the photon-flux variants.
+ * The six optional pointers are given all together or all NULL (then this is crt_hip_absorb_bandsum_f64); totals may be NULL.
+ */
+typedef struct crt_bandsum_out {
+  double* aI;      /* [ncol][nz-1][ngroup] */
+  double* aI_sl;
+  double* aI_sh;
+  double* totals;  /* [ncol][ngroup][4] or NULL */
+  double* aI_dr;   /* [ncol][nz-1][ngroup] or NULL */
+  double* I_dr;    /* [ncol][nz][ngroup] or NULL */
+  double* I_df_d;
+  double* I_df_u;
+  double* F;
+  double* I_d;
+} crt_bandsum_out;
+int crt_hip_absorb_bandsum2_f64(const crt_columns* cols, const crt_bands* bands, const double* I_dr, const double* I_df_d,
+                                const double* I_df_u, const double* band_w, int32_t ngroup, const crt_bandsum_out* out, crt_stream_t stream);
+/* ... and the same complete output from the fused solve + epilogue (crt_hip_integrated_f64): no profile is written to memory, the
+ * level sums the kernel forms anyway are kept instead of thrown away. */
+int crt_hip_integrated2_f64(int scheme, const crt_columns* cols, const crt_bands* bands, const crt_options* opts, const double* band_w,
+                            int32_t ngroup, const crt_bandsum_out* out, void* workspace, size_t workspace_bytes, crt_stream_t stream);
+
+/*
  * Fused solve + epilogue: the integrated outputs of crt_hip_absorb_bandsum_f64 (same shapes and meaning) straight from
  * the inputs, WITHOUT writing any profile to memory (bytes per solve drop from ~2 kB to ~40 B; the variant SURVEY.md
  * section 8(d) asks to report separately).  Schemes: 2s, 4s, bl, g77, bf, n79, zq; nb <= 1024.
@@ -211,6 +240,14 @@ int crt_hip_absorb_bandsum_f64(const crt_columns* cols, const crt_bands* bands, 
 int crt_hip_integrated_f64(int scheme, const crt_columns* cols, const crt_bands* bands, const crt_options* opts,
                            const double* band_w, int32_t ngroup, double* aI, double* aI_sl, double* aI_sh, double* totals,
                            void* workspace, size_t workspace_bytes, crt_stream_t stream);
+
+/*
+ * diagnostics.band's reduction for ANY variable with a trailing wavelength axis (diagnostics.py:81, `(da * w).sum(dim="wl")`):
+ * out[row][g] = sum_b band_w[g][b] X[row][b], X = [nrow][nb], band_w = [ngroup <= 4][nb], out = [nrow][ngroup].  Used by
+ * crt1d_amd.diagnostics.band for the variables of a single Model's dataset (incl. the schemes' own aI_*_scheme outputs); the batched
+ * path uses crt_hip_absorb_bandsum2_f64 / crt_hip_integrated2_f64.
+ */
+int crt_hip_band_reduce_f64(const double* X, int64_t nrow, int32_t nb, const double* band_w, int32_t ngroup, double* out, crt_stream_t stream);
 
 /*
  * Per-band layer absorption (model.py:573-647 `_calc_absorption`): out7 = {aI, aI_df, aI_dr, aI_sh, aI_sl, aI_df_sl,

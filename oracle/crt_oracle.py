@@ -753,6 +753,32 @@ def band_sum(X, wle, band_name="PAR", bounds=None):
     return X @ x_frac_in_bounds(wle, bounds)
 
 
+def e_wl_umol(wl_um):
+    """J per micromole of photons at wavelength wl_um (micrometres); spectra.py:30-39 (CODATA 2018 exact h, c, N_A, the values
+    scipy.constants holds).  Known answer: reference tests/test_spectra.py:75-79."""
+    wl = np.asarray(wl_um, dtype=np.float64) * 1e-6
+    return 6.62607015e-34 * 299792458.0 / wl * 6.02214076e23 * 1e-6
+
+
+def band_profiles(sol, absorption, wle, names=("PAR", "NIR", "solar"), *, wl=None, pfd=False):
+    """Everything diagnostics.band returns for the "I..." / "F" variables of one run (diagnostics.py:39-108): for every variable
+    X (..., n_wl) the stack over band groups of sum_wl w X (:81); pfd=True: of sum_wl w (X / e_wl_umol(wl)) (:19-36, :92-104)."""
+    W = np.stack([x_frac_in_bounds(wle, BAND_DEFNS_UM[n]) for n in names])
+    if pfd:
+        wle_ = np.asarray(wle, dtype=np.float64)
+        wl = 0.5 * (wle_[:-1] + wle_[1:]) if wl is None else np.asarray(wl, dtype=np.float64)
+        f = 1.0 / e_wl_umol(wl)
+    var = {k: sol[k] for k in ("I_dr", "I_df_d", "I_df_u", "F")}
+    var["I_d"] = sol["I_dr"] + sol["I_df_d"]  # model.py:425
+    var.update({k: v for k, v in absorption.items() if k.startswith("aI")})
+    out = {}
+    for k, X in var.items():
+        Xf = X * f if pfd else X
+        # (the reference names the photon-flux variants vn.replace("I", "PFD"); "F" keeps its name and is overwritten in its dataset)
+        out[k.replace("I", "PFD") if pfd and k != "F" else k] = np.stack([(Xf * w).sum(axis=-1) for w in W], axis=-1)  # (..., ngroup)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # Input side (SURVEY.md section 8(f) rank 4)
 def smear_tuv(x, y, bins):

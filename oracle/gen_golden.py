@@ -273,7 +273,7 @@ def g9(la, out):
     print("wrote", out / "g9_common.npz")
 
 
-def reference_functions(path, names):
+def reference_functions(path, names, extra=None):
     """Compile the named top-level function definitions / assignments of a reference source file (build container only) without
     importing the module (its top-level ``import xarray`` fails here with an ordinary ModuleNotFoundError)."""
     import ast
@@ -285,6 +285,7 @@ def reference_functions(path, names):
             or (isinstance(n, ast.Assign) and any(isinstance(t, ast.Name) and t.id in names for t in n.targets))]
     assert len(keep) == len(names), [getattr(n, "name", None) for n in keep]
     ns = {"np": np, "warnings": _w}
+    ns.update(extra or {})
     exec(compile(ast.Module(body=keep, type_ignores=[]), str(REF / path), "exec"), ns)
     return ns
 
@@ -344,6 +345,52 @@ def g6(la, lar, sol, out):
     save(out, "g6_absorption", **arrays)
 
 
+def g10(la, lar, sol, out):
+    """Row a12 completed + the input side: what the reference's `diagnostics.band` returns for its "I..." / "F" variables
+    (diagnostics.py:81 `(da * w).sum(dim="wl")`; with calc_PFD `_E_to_PFD_da` first, :19-36, :92-104), formed with the reference's own
+    `_x_frac_in_bounds` and `e_wl_umol` (compiled from crt1d/spectra.py where it lies) on the reference solvers' profiles and the
+    reference's `_calc_absorption`; and `smear_tuv` (spectra.py:221-300) on seeded random spectra."""
+    import scipy.constants as sc
+    from types import SimpleNamespace
+
+    calc = reference_functions("crt1d/model.py", ["_calc_absorption"])["_calc_absorption"]
+    sp = reference_functions("crt1d/spectra.py", ["_x_frac_in_bounds", "BAND_DEFNS_UM", "e_wl_umol", "_smear_tuv_1", "smear_tuv"],
+                             extra=dict(h=sc.h, c=sc.c, N_A=sc.N_A))
+    xfrac, defs, e_umol = sp["_x_frac_in_bounds"], sp["BAND_DEFNS_UM"], sp["e_wl_umol"]
+    p = default_case_inputs(la, lar)
+    lai = p["lai"]
+    p["dlai"] = lai[:-1] - lai[1:]
+    p["K_b"] = p["K_b_fn"](p["psi"])
+    wl = p["wl"]
+    wle = np.r_[wl[0] - 0.5 * p["dwl"][0], wl + 0.5 * p["dwl"]]  # model.py:287
+    names = ("PAR", "NIR", "solar")
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        W = np.stack([xfrac(wle, defs[n]) for n in names])
+    f = 1 / e_umol(wl)  # diagnostics.py:27
+    arrays = dict(wl=wl, wle=wle, band_names=np.array(names), w=W, e_wl_umol=e_umol(wl), e_wl_umol_at_3um=np.array(e_umol(3)))
+    for s in ("2s", "n79", "zq", "4s"):
+        r = run_scheme(sol, s, p)
+        prof = {k: r[k] for k in ("I_dr", "I_df_d", "I_df_u", "F")}
+        prof["I_d"] = r["I_dr"] + r["I_df_d"]  # model.py:425
+        m = SimpleNamespace(_p=p, out={k: r[k] for k in ("I_dr", "I_df_d", "I_df_u")})
+        prof.update({k: v for k, v in calc(m).items() if k.startswith("aI")})
+        for k, da in prof.items():
+            arrays[f"{s}__{k}__band"] = np.stack([(da * w).sum(axis=-1) for w in W])                 # :81
+            # :93-97 (da_pfd = da * f, :31).  (In the dataset the reference names it vn.replace("I", "PFD") -- which for "F" is "F"
+            # again: with calc_PFD its F is overwritten by the photon-flux version.  Stored here under separate keys.)
+            arrays[f"{s}__{k}__band_pfd"] = np.stack([((da * f) * w).sum(axis=-1) for w in W])
+        print("  g10", s)
+    rng = np.random.default_rng(77)
+    x = np.sort(rng.uniform(0.28, 2.7, 400))
+    y = rng.uniform(0.0, 2.0, (5, 400)) * np.exp(-((x - 0.9) ** 2))[None, :]
+    bins = np.r_[0.25, np.sort(rng.uniform(0.3, 2.6, 40)), 2.9]  # first / last bin reach beyond the data
+    arrays.update(smear_x=x, smear_y=y, smear_bins=bins, smear_out=np.stack([sp["smear_tuv"](x, yy, bins) for yy in y]))
+    save(out, "g10_band_profiles", **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(REPO / "tests" / "golden"))
@@ -389,6 +436,8 @@ def main():
         g8(lar, out)
     if want("g9"):
         g9(la, out)
+    if want("g10"):
+        g10(la, lar, sol, out)
 
 
 if __name__ == "__main__":

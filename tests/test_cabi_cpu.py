@@ -43,12 +43,17 @@ def test_struct_layouts_match_header(lib):
     assert ctypes.sizeof(_lib.CrtBands) == 8 + 8 + 5 * 8
     assert ctypes.sizeof(_lib.CrtOptions) == 16 + 4 * _lib.NTUNE  # mu_s, tau_d_method, flags, tune[CRT_NTUNE]
     assert ctypes.sizeof(_lib.CrtOutputs) == 7 * 8
+    assert ctypes.sizeof(_lib.CrtBandsumOut) == 10 * 8
+    # field order of the header's struct
+    text = open(os.path.join(ROOT, "include", "crt1d_hip.h")).read()
+    body = text[text.index("typedef struct crt_bandsum_out {"):text.index("} crt_bandsum_out;")]
+    assert re.findall(r"double\* (\w+);", body) == [f[0] for f in _lib.CrtBandsumOut._fields_]
 
 
 def test_host_only_entry_points(lib):
     from crt1d_amd import _lib
 
-    assert lib.crt_hip_abi_version() == 2
+    assert lib.crt_hip_abi_version() == _lib.ABI_VERSION == 3
     assert isinstance(lib.crt_hip_last_kernel(), bytes)  # reporting hook; empty before the first solve
     assert _lib.strerror(0) == "ok" and "workspace" in _lib.strerror(_lib.CRT_ERR_WORKSPACE)
     # record = 16-double header + nvec * nz

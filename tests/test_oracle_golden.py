@@ -253,3 +253,34 @@ def test_ref_shaped_2s_equals_oracle(oracle):
     for k, v in res.items():
         assert rel_profile_err(v, vec[k][0]) <= 1e-13, k
         assert rel_profile_err(v, g[f"2s__{k}"]) <= 1e-11, k
+
+
+def test_band_profiles_and_pfd_vs_reference_g10(oracle):
+    """Row a12 complete: the oracle's restatement of diagnostics.band (every "I..." / "F" variable, W m-2 and photon-flux variants)
+    against values formed with the REFERENCE's own _x_frac_in_bounds / e_wl_umol on the reference's profiles (g10, oracle/gen_golden.py)."""
+    g1, g10 = load_golden("g1_default"), load_golden("g10_band_profiles")
+    O = oracle
+    wl, wle = g10["wl"], g10["wle"]
+    assert np.array_equal(O.e_wl_umol(wl), g10["e_wl_umol"])  # bit for bit: same constants, same operation order
+    # the reference's own known answer (tests/test_spectra.py:75-79)
+    assert abs(float(O.e_wl_umol(3)) / (6.621e-20 * 6.02214076e23 / 1e6) - 1) < 1e-4
+    names = [str(n) for n in g10["band_names"]]
+    cols = O.Columns(np.atleast_1d(g1["psi"]), g1["lai"][None, :], mla=np.atleast_1d(g1["mla"]), g_kind=np.array([4], dtype=np.int32),
+                     g_param=np.atleast_1d(g1["x"]))
+    for s in ("2s", "n79", "zq"):
+        sol = {k: g1[f"{s}__{k}"][None] for k in ("I_dr", "I_df_d", "I_df_u", "F")}
+        ab = O.calc_absorption(cols, sol, leaf_r=g1["leaf_r"][None], leaf_t=g1["leaf_t"][None])
+        for pfd in (False, True):
+            got = O.band_profiles(sol, ab, wle, names, wl=wl, pfd=pfd)
+            for k, v in got.items():
+                ref = g10[f"{s}__{k.replace('PFD', 'I')}__band" + ("_pfd" if pfd else "")]  # (ngroup, nlev)
+                err = np.abs(v[0].T - ref).max() / np.abs(ref).max()
+                assert err <= 1e-13, (s, k, pfd, err)
+
+
+def test_smear_tuv_vs_reference_g10(oracle):
+    """oracle.smear_tuv against the reference's smear_tuv (spectra.py:221-300, compiled where it lies by oracle/gen_golden.py) on
+    seeded random spectra with bins reaching beyond the data: identical arithmetic, identical bits."""
+    g10 = load_golden("g10_band_profiles")
+    for y, ref in zip(g10["smear_y"], g10["smear_out"]):
+        assert np.array_equal(oracle.smear_tuv(g10["smear_x"], y, g10["smear_bins"]), ref)
