@@ -110,10 +110,12 @@ __device__ __forceinline__ void tri_wave_body(const SolveArgs& a, const Item& it
   const double bc = st.band_const(), invmu = rec[S_INVMU];
 
   double e, f;
-  st.first(rec, nz, e, f);
+  typename S::St fs;
+  st.first(rec, nz, fs);
+  st.pair(fs, e, f);
   for (int k = 0; k + 1 < K; ++k) {
     ef.put(k, e, f);
-    st.advance(k, rec, nz, e, f);
+    tri_step(st, k, rec, nz, fs, e, f);  // the same operations, re-seeding schedule included, as the column-tile kernels
   }
   double v[S::NST];
   st.top(rec, nz, e, f, v);

@@ -26,8 +26,82 @@ __device__ inline TriBand load_tri_band(const SolveArgs& a, int c, int b) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The forward recurrence of both schemes maps the even-row pair (e, f) of level k to that of level k + 1 by a LINEAR FRACTIONAL
+// transformation: e' = (a e + b) / (c e + d), f' = (alpha f + beta(e)) / (c e + d).  Written for e = p / q, f = g / q it is a linear
+// recurrence in (p, q, g) WITHOUT a division: the serial dependency chain of a step is 3-5 multiply-adds instead of ~12 operations
+// with a reciprocal in the middle (the sweeps are latency-bound: zq_pa spent a third of a workgroup's life in its forward sweep,
+// DESIGN 3.7).  A scheme therefore carries a state St through its sweep:
+//   first(rec, nz, St&)            state of level 0
+//   advance(k, rec, nz, St&)       level k -> level k + 1
+//   pair(St, e, f)                 the normalised pair (e, f) = (p / q, g / q) of the state's level -- one reciprocal, OFF the chain
+//   seed(St&, e, f)                state (e, 1, f)
+// and the chain is re-seeded from its own normalised pair every RENORM-th level (tri_advance / tri_step below): (p, q, g) shrink or grow
+// by a bounded factor per level, so nothing over- or underflows in between, and because the schedule depends on the level index only --
+// and every checkpoint spacing M in use is a multiple of RENORM -- a recomputation that starts from a checkpoint's (e, 1, f) repeats the
+// forward sweep's operations exactly: every kernel family produces the same bits.  (RENORM = 0: the state IS the pair; n79.)
+template <class S>
+__device__ __forceinline__ void tri_advance(const S& st, int k, const double* rec, int nz, typename S::St& s) {
+  st.advance(k, rec, nz, s);
+  if constexpr (S::RENORM > 0) {
+    if ((k + 1) % S::RENORM == 0) {
+      double e, f;
+      st.pair(s, e, f);
+      st.seed(s, e, f);
+    }
+  }
+}
+// The forward sweep from level 0 (state of first()) to level k1, in groups of RENORM levels with the re-seeding at the end of each group
+// -- as straight-line code: written as "if ((k + 1) % RENORM == 0)" inside a per-level loop the compiler if-converts the branch and
+// evaluates the reciprocal of pair() at EVERY level, back on the chain (ISA of k_zqpa_pipe, round 3).  on_checkpoint(level, state) is
+// called at every level that is a multiple of M (state freshly re-seeded there when M is a multiple of RENORM).
+template <class S, int M, class F>
+__device__ __forceinline__ void tri_forward(const S& st, const double* rec, int nz, typename S::St& s, int k1, F&& on_checkpoint) {
+  if constexpr (S::RENORM > 0 && M % (S::RENORM > 0 ? S::RENORM : 1) == 0) {
+    constexpr int R = S::RENORM;
+    int k = 0;
+    for (; k + R <= k1; k += R) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) st.advance(k + i, rec, nz, s);
+      double e, f;
+      st.pair(s, e, f);
+      st.seed(s, e, f);
+      if ((k + R) % M == 0) on_checkpoint(k + R, s);
+    }
+    for (; k < k1; ++k) st.advance(k, rec, nz, s);  // fewer than RENORM levels left: no re-seeding level, no checkpoint among them
+  } else {
+    for (int k = 0; k < k1; ++k) {
+      tri_advance(st, k, rec, nz, s);
+      if ((k + 1) % M == 0) on_checkpoint(k + 1, s);
+    }
+  }
+}
+// ... and the same step returning the normalised pair of level k + 1
+template <class S>
+__device__ __forceinline__ void tri_step(const S& st, int k, const double* rec, int nz, typename S::St& s, double& e, double& f) {
+  st.advance(k, rec, nz, s);
+  st.pair(s, e, f);
+  if constexpr (S::RENORM > 0) {
+    if ((k + 1) % S::RENORM == 0) st.seed(s, e, f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // n79 (crt1d/solvers/_solve_n79.py:70-155).  Even row k <-> upward flux at level k, k = 0 .. nz-1.
 struct TriN79 {
+  struct St {
+    double e, f;
+  };
+  static constexpr int RENORM = 0;
+  __device__ static inline void pair(const St& s, double& e, double& f) {
+    e = s.e;
+    f = s.f;
+  }
+  __device__ static inline void seed(St& s, double e, double f) {
+    s.e = e;
+    s.f = f;
+  }
+  __device__ inline void first(const double* rec, int nz, St& s) const { first(rec, nz, s.e, s.f); }
+  __device__ inline void advance(int k, const double* rec, int nz, St& s) const { advance(k, rec, nz, s.e, s.f); }
   static constexpr const char* NAME = "n79";
   static constexpr int NST = 4;   // staged: dn, up, aI_lsl, aI_lsh
   static constexpr int NOUT = 6;  // I_dr, I_df_d, I_df_u, F, aI_lsl, aI_lsh
@@ -155,6 +229,8 @@ struct TriN79 {
 struct TriN79U : TriN79 {
   double r, s, rr, k_odd, k_even, omtb;        // advance
   double refld, k_dn, k_src, itrand, omt_oma;  // back
+  __device__ inline void first(const double* rec, int nz, St& st) const { TriN79::first(rec, nz, st.e, st.f); }
+  __device__ inline void advance(int k, const double* rec, int nz, St& st) const { advance(k, rec, nz, st.e, st.f); }
   template <typename TIO>
   __device__ inline void init(const double* rec, const SolveArgs& a, int c, int b) {
     init_band(rec, a, load_tri_band<TIO>(a, c, b));
@@ -213,6 +289,7 @@ struct TriZq {
   static constexpr int NST = 4;   // staged: I_df_d, I_df_u, I_df_d_ss, I_df_u_ss
   static constexpr int NOUT = 7;  // I_dr, I_df_d, I_df_u, F, I_df_d_ss, I_df_u_ss, F_ss
   double I_dr0, I_df0, rho, fwd, q, q0, cu, cd, invmu;
+  double idq;     // 1 / (1 - q^2): dlo = dhi = 1 - q^2 on every interior level -- their two reciprocals per back step become none
   double xd, xu;  // SWd0[li], SWu0[li] of the level above
 
   __host__ __device__ static inline int rows(int nz) { return nz + 1; }
@@ -238,27 +315,46 @@ struct TriZq {
     q0 = 1.0 * (1 - (1 - rho)) * (1 - 0.0);  // ground "layer": r=1, t=0, a=1-rho (:106-108)
     cu = r_psi * (1 - t_psi) * (1 - aL);        // :139
     cd = (1 - t_psi) * (1 - aL) * (1 - r_psi);  // :142
+    idq = fast_rcp(__builtin_fma(-q, q, 1.0));
   }
-  __device__ inline void first(const double* rec, int nz, double& e, double& f) const {
-    e = 0.0;  // row 0: x0 = rho S_0 (:115,136)
-    f = rho * (I_dr0 * rec[REC_HDR]);
+  // state of the forward sweep: e = p / q, f = g / q (see the note above tri_advance)
+  struct St {
+    double p, q, g;
+  };
+  static constexpr int RENORM = 4;
+  __device__ static inline void pair(const St& s, double& e, double& f) {
+    const double iq = fast_rcp(s.q);
+    e = s.p * iq;
+    f = s.g * iq;
+  }
+  __device__ static inline void seed(St& s, double e, double f) {
+    s.p = e;
+    s.q = 1.0;
+    s.g = f;
+  }
+  __device__ inline void first(const double* rec, int nz, St& s) const {
+    s.p = 0.0;  // row 0: x0 = rho S_0 (:115,136)
+    s.q = 1.0;
+    s.g = rho * (I_dr0 * rec[REC_HDR]);
   }
   // even pair of li-1 -> even pair of li: rows 2li-1 (sub -fwd, dia -qlo fwd, sup dlo; :116-118, rhs :137-139) and
-  // 2li (sub dhi, dia -qhi fwd, sup -fwd; :119-121, rhs :140-142) of the sweep, merged into one rational update:
-  //   B = fwd (e - qlo),  D = qhi fwd B + dhi dlo,   e' = fwd B / D,   f' = (dhi (C1 + fwd f) - C2 B) / D
-  __device__ inline void advance(int k, const double* rec, int m, double& e, double& f) const {
+  // 2li (sub dhi, dia -qhi fwd, sup -fwd; :119-121, rhs :140-142) of the sweep, merged into one rational update
+  //   B = fwd (e - qlo),  D = qhi fwd B + dhi dlo,   e' = fwd B / D,   f' = (dhi (C1 + fwd f) - C2 B) / D,   C1 = dlo cu S, C2 = dhi cd S
+  // and multiplied through by q (e = p / q, f = g / q):   u = p - qlo q,
+  //   p' = fwd^2 u,   q' = qhi p' + dhi dlo q,   g' = dhi (fwd g + S (dlo cu q - cd fwd u))
+  __device__ inline void advance(int k, const double* rec, int m, St& s) const {
     const int li = k + 1;
     const double S = I_dr0 * rec[REC_HDR + li - 1];  // :130
     const double qlo = (li == 1) ? q0 : q;
     const double qhi = (li == m) ? 0.0 : q;
     const double dlo = __builtin_fma(-qlo, q, 1.0);  // :118
     const double dhi = __builtin_fma(-q, qhi, 1.0);  // :119
-    const double C1 = dlo * cu * S;
-    const double C2 = dhi * cd * S;
-    const double B = fwd * (e - qlo);
-    const double iD = fast_rcp(__builtin_fma(qhi * fwd, B, dhi * dlo));
-    e = fwd * B * iD;
-    f = __builtin_fma(dhi, __builtin_fma(fwd, f, C1), -(C2 * B)) * iD;
+    const double u = __builtin_fma(-qlo, s.q, s.p);
+    const double pn = (fwd * fwd) * u;
+    const double t = __builtin_fma(dlo * cu, s.q, -((cd * fwd) * u));
+    s.g = dhi * __builtin_fma(fwd, s.g, S * t);
+    s.q = __builtin_fma(qhi, pn, (dhi * dlo) * s.q);
+    s.p = pn;
   }
   // k = m: x[2m+1] = I_df0 (:122,143); no output row at k = m
   __device__ inline void top(const double* rec, int m, double e, double f, double (&o)[NST]) {
@@ -276,9 +372,12 @@ struct TriZq {
     // SWd0[li-1] from the original row 2li:  dhi x_{2li-1} - qhi fwd x_{2li} - fwd x_{2li+1} = C
     // (1/dhi and 1/dlo take three values per band; keeping them in registers costs the integrated kernel a wave of
     // occupancy -- 96 -> 98 VGPRs, 1.19 -> 1.45 ms -- and the profile kernels are store-bound, so they are recomputed)
-    const double xdl = __builtin_fma(dhi * cd, S, fwd * __builtin_fma(qhi, xu, xd)) * fast_rcp(dhi);
+    // (the level index is the same for every lane: a scalar branch picks the interior's precomputed reciprocal -- the same value,
+    //  fast_rcp of the same 1 - q^2, as the boundary path would compute)
+    const bool interior = li != 1 && li != m;
+    const double xdl = __builtin_fma(dhi * cd, S, fwd * __builtin_fma(qhi, xu, xd)) * (interior ? idq : fast_rcp(dhi));
     const double xul = __builtin_fma(-e, xdl, f);  // SWu0[li-1]
-    const double iden = fast_rcp(dlo);   // multiple-scattering correction, eqs. 24/25 (:180-187)
+    const double iden = interior ? idq : fast_rcp(dlo);   // multiple-scattering correction, eqs. 24/25 (:180-187)
     o[0] = __builtin_fma(q, xul, xd) * iden;
     o[1] = __builtin_fma(qlo, xd, xul) * iden;
     o[2] = xd;   // I_df_d_ss :197

@@ -266,19 +266,23 @@ __device__ __forceinline__ void tri_tile_body(const SolveArgs& a, const TriCfg& 
   if (active) bandc[b] = st.band_const();
   const int K = S::rows(nz);
 
-  // ---- pass 1: forward recurrence, keep the even-row pair of every M-th level ----
-  double e, f;
-  st.first(rec, nz, e, f);
-  ck[0] = e;
-  ck[nthr] = f;
-  for (int k = 0; k + 1 < K; ++k) {
-    st.advance(k, rec, nz, e, f);
-    if ((k + 1) % M == 0) {
-      const int s = (k + 1) / M;
-      ck[(2 * s) * nthr] = e;
-      ck[(2 * s + 1) * nthr] = f;
-    }
+  // ---- pass 1: forward recurrence (state St, tri_schemes.hpp), keep the even-row pair of every M-th level ----
+  static_assert(S::RENORM == 0 || M % S::RENORM == 0, "checkpoints must fall on re-seeding levels");
+  typename S::St fs;
+  st.first(rec, nz, fs);
+  {
+    double e, f;
+    st.pair(fs, e, f);
+    ck[0] = e;
+    ck[nthr] = f;
   }
+  tri_forward<S, M>(st, rec, nz, fs, K - 1, [&](int level, const typename S::St& cs) {
+    const int s = level / M;
+    double e, f;
+    st.pair(cs, e, f);
+    ck[(2 * s) * nthr] = e;
+    ck[(2 * s + 1) * nthr] = f;
+  });
 
   // ---- pass 2: segments from the top; recompute the segment's pairs into registers, back-substitute, flush ----
   for (int seg = (K - 1) / M; seg >= 0; --seg) {
@@ -287,11 +291,13 @@ __device__ __forceinline__ void tri_tile_body(const SolveArgs& a, const TriCfg& 
     double be[M], bf[M];  // pairs of levels k0 .. k0+M-1 (statically indexed: the loops below are fully unrolled)
     be[0] = ck[(2 * seg) * nthr];
     bf[0] = ck[(2 * seg + 1) * nthr];
+    typename S::St rs;
+    st.seed(rs, be[0], bf[0]);
 #pragma unroll
     for (int i = 1; i < M; ++i) {
       be[i] = be[i - 1];
       bf[i] = bf[i - 1];
-      if (k0 + i <= kend) st.advance(k0 + i - 1, rec, nz, be[i], bf[i]);
+      if (k0 + i <= kend) tri_step(st, k0 + i - 1, rec, nz, rs, be[i], bf[i]);
     }
 #pragma unroll
     for (int i = M - 1; i >= 0; --i) {
@@ -404,29 +410,35 @@ __device__ __forceinline__ void tri_int_body(const SolveArgs& a, const IntArgs& 
       }
     }
   const int K = S::rows(nz);
-  double e, f;
-  st.first(rec, nz, e, f);
-  ck[0] = e;
-  ck[nthr] = f;
-  for (int k = 0; k + 1 < K; ++k) {
-    st.advance(k, rec, nz, e, f);
-    if ((k + 1) % M == 0) {
-      const int sidx = (k + 1) / M;
-      ck[(2 * sidx) * nthr] = e;
-      ck[(2 * sidx + 1) * nthr] = f;
-    }
+  static_assert(S::RENORM == 0 || M % S::RENORM == 0, "checkpoints must fall on re-seeding levels");
+  typename S::St fs;
+  st.first(rec, nz, fs);
+  {
+    double e, f;
+    st.pair(fs, e, f);
+    ck[0] = e;
+    ck[nthr] = f;
   }
+  tri_forward<S, M>(st, rec, nz, fs, K - 1, [&](int level, const typename S::St& cs) {
+    const int sidx = level / M;
+    double e, f;
+    st.pair(cs, e, f);
+    ck[(2 * sidx) * nthr] = e;
+    ck[(2 * sidx + 1) * nthr] = f;
+  });
   for (int seg = (K - 1) / M; seg >= 0; --seg) {
     const int k0 = seg * M;
     const int kend = min(k0 + M - 1, K - 1);
     double be[M], bf[M];
     be[0] = ck[(2 * seg) * nthr];
     bf[0] = ck[(2 * seg + 1) * nthr];
+    typename S::St rs;
+    st.seed(rs, be[0], bf[0]);
 #pragma unroll
     for (int i = 1; i < M; ++i) {
       be[i] = be[i - 1];
       bf[i] = bf[i - 1];
-      if (k0 + i <= kend) st.advance(k0 + i - 1, rec, nz, be[i], bf[i]);
+      if (k0 + i <= kend) tri_step(st, k0 + i - 1, rec, nz, rs, be[i], bf[i]);
     }
 #pragma unroll
     for (int i = M - 1; i >= 0; --i) {
@@ -542,6 +554,16 @@ __device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeC
   const int tstride = T * nb, bstride = NSTG * tstride;  // NSTG: staged arrays kept in the tile (the first NSTG of NST)
   const bool active = tid < nb;
   const int b = active ? tid : 0;
+#ifdef CRT_STAMP
+  // diagnostic build only (tools/stamp_timeline.py --tri): wall_clock64 stamps of compute wave 0, written over the column's own K0 record
+  // in the workspace (already staged in LDS; K0 rewrites it) -- never into an output
+  double* stamp = const_cast<double*>(a.ws) + (long long)c * a.reclen;
+  int nstamp = 0;
+#define TSTAMP() do { if (tid == 0 && nstamp < a.reclen) stamp[nstamp++] = (double)wall_clock64(); } while (0)
+#else
+#define TSTAMP() do {} while (0)
+#endif
+  TSTAMP();  // [0] record staged
   S st;
   if (band)  // requested by the kernel together with the record (zq_pa)
     st.init_band(rec, a, *band);
@@ -549,47 +571,57 @@ __device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeC
     st.template init<TIO>(rec, a, c, b);
   if (active) bandc[b] = st.band_const();
   const int K = S::rows(nz);
-  double e, f;
+  TSTAMP();  // [1] band set-up done
   // Forward sweep.  Checkpoints (every M levels) are kept for the segments 1 .. top-1 only: segment 0 restarts from first() and the TOP
   // segment -- the first one to be substituted back -- is left in registers by the sweep itself, so it is neither stored nor recomputed
   // (two checkpoint pairs per lane less = 10 KB of LDS at 300 bands; up to M - 1 level steps less before the first tile is handed over).
   const int seg_top = (K - 1) / M, k_top = seg_top * M;
   double be[M], bf[M];  // (e, f) of the levels of the segment being substituted back
-  st.first(rec, nz, e, f);
-  for (int k = 0; k < k_top; ++k) {
-    st.advance(k, rec, nz, e, f);
-    if ((k + 1) % M == 0 && k + 1 < k_top) {
-      const int sidx = (k + 1) / M - 1;  // checkpoint of segment sidx + 1
+  // (M a multiple of the scheme's re-seeding interval: every kernel family then repeats the same operations, tri_schemes.hpp.  zq_pa's
+  //  M = 15 form is the exception: its segments restart from (e, 1, f) off the schedule -- equal to the other forms to rounding, not bitwise)
+  typename S::St fs;
+  st.first(rec, nz, fs);
+  tri_forward<S, M>(st, rec, nz, fs, k_top, [&](int level, const typename S::St& cs) {
+    if (level < k_top) {
+      const int sidx = level / M - 1;  // checkpoint of segment sidx + 1
+      double e, f;
+      st.pair(cs, e, f);
       ck[(2 * sidx) * nthr] = e;
       ck[(2 * sidx + 1) * nthr] = f;
     }
-  }
-  be[0] = e;
-  bf[0] = f;
+  });
+  st.pair(fs, be[0], bf[0]);
+  if constexpr (S::RENORM > 0 && M % (S::RENORM > 0 ? S::RENORM : 1) != 0) st.seed(fs, be[0], bf[0]);  // off-schedule segment start
 #pragma unroll
   for (int i = 1; i < M; ++i) {
     be[i] = be[i - 1];
     bf[i] = bf[i - 1];
-    if (k_top + i <= K - 1) st.advance(k_top + i - 1, rec, nz, be[i], bf[i]);
+    if (k_top + i <= K - 1) tri_step(st, k_top + i - 1, rec, nz, fs, be[i], bf[i]);
   }
+  TSTAMP();  // [2] forward sweep done (top segment in registers)
   int buf = 0;
   for (int seg = seg_top; seg >= 0; --seg) {
     const int k0 = seg * M;
     const int kend = min(k0 + M - 1, K - 1);
+    TSTAMP();  // per segment: start
     if (seg != seg_top) {
+      typename S::St rs;
       if (seg == 0) {
-        st.first(rec, nz, be[0], bf[0]);
+        st.first(rec, nz, rs);
+        st.pair(rs, be[0], bf[0]);
       } else {
         be[0] = ck[(2 * (seg - 1)) * nthr];
         bf[0] = ck[(2 * (seg - 1) + 1) * nthr];
+        st.seed(rs, be[0], bf[0]);
       }
 #pragma unroll
       for (int i = 1; i < M; ++i) {
         be[i] = be[i - 1];
         bf[i] = bf[i - 1];
-        if (k0 + i <= kend) st.advance(k0 + i - 1, rec, nz, be[i], bf[i]);
+        if (k0 + i <= kend) tri_step(st, k0 + i - 1, rec, nz, rs, be[i], bf[i]);
       }
     }
+    TSTAMP();  // per segment: pairs recomputed
 #pragma unroll
     for (int i = M - 1; i >= 0; --i) {
       const int k = k0 + i;
@@ -604,11 +636,13 @@ __device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeC
           for (int q = 0; q < NSTG; ++q) tile[buf * bstride + q * tstride + (i % T) * nb + b] = o[q];
         }
         if (i % T == 0) {  // tile complete: hand it to the store waves
+          TSTAMP();  // per tile: substituted back
           lds_barrier();
           if constexpr (RS > 0)
             lds_barrier();  // single buffer: wait until the store waves hold the tile in registers
           else
             buf ^= 1;
+          TSTAMP();  // per tile: handed over
         }
       }
     }

@@ -263,6 +263,237 @@ __device__ __forceinline__ void zqpa_pipe_store_flat(const SolveArgs& a, const P
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 3: the interpolation moves INTO the compute lanes.  Timeline of the kernel above (tools/stamp_timeline_tri.py, 1e4 x 300 x 60):
+// of a column's 71 us the compute waves spend 11 in the forward sweep, 7 recomputing pairs, 15 substituting back -- and 35 waiting at the
+// hand-over barriers for the store waves, whose per-element work (index search, halo selection, four row reads, two interpolations) is
+// what bounds the kernel.  But the interpolation runs along the LEVEL axis of one band, i.e. inside a lane of the compute role: the lane
+// keeps the two fluxes of the last three computational rows in registers (output level j needs rows max(ka - 2, 0) .. ka, ka = kidx[j])
+// and, walking down, emits every output level as soon as its lowest row exists.  The LDS tile then holds FINISHED output levels (I_df_d,
+// I_df_u), T of them, and the store role is the plain fused flush of the other tridiagonal schemes (I_dr and F formed while flushing):
+// ZqPaOut below is that role's view of the outputs.  Same expressions as k_zqpa_interp -> the same bits as the two-kernel path.
+struct ZqPaOut {
+  static constexpr const char* NAME = "zq_pa";
+  static constexpr int NST = 2;   // staged: I_df_d, I_df_u
+  static constexpr int NOUT = 4;  // I_dr, I_df_d, I_df_u, F
+  __host__ __device__ static inline int rows(int nz) { return nz; }
+  __host__ __device__ static constexpr int out_rows(int, int nz) { return nz; }
+  // (record of scheme zq_pa: vector 1 = e^{-K_b lai_j} on the caller's levels)
+  __device__ static inline void emit(const double* rec, int nz, int j, d2 bc, double invmu_, const d2 (&st)[NST], d2 (&o)[NOUT]) {
+    const d2 idr = bc * rec[REC_HDR + nz + j];  // :354-355
+    o[0] = idr;
+    o[1] = st[0];
+    o[2] = st[1];
+    o[3] = idr * invmu_ + 2 * st[1] + 2 * st[0];  // :412
+  }
+};
+
+// compute role: the zq system on the computational grid (g.nz = Mg rows + 1), checkpointed like tri_pipe_compute, with the emission of
+// interpolated output levels behind every back-substitution step.  RS > 0: single tile buffer (two barriers per hand-over).
+template <typename TIO, int M, int T, int RS>
+__device__ __forceinline__ void zqpa_compute(const SolveArgs& g, const PipeCfg& cfg, double* lds, const TriBand& band) {
+  typedef TriZq S;
+  const int nb = g.nb, Mg = g.nz, nzo = cfg.nz_out;
+  const int tid = threadIdx.x, nthr = cfg.ncomp;
+  const double* rec = lds;
+  double* bandc = lds + cfg.off_bc;
+  double* ck = lds + cfg.off_ck + tid;
+  double* tile = lds + cfg.off_tile;  // [RS > 0 ? 1 : 2][2][T][nb]
+  const int tstride = T * nb, bstride = 2 * tstride;
+  const double* kidx = rec + REC_HDR + 2 * nzo;
+  const double* wgt = kidx + nzo;
+  const bool active = tid < nb;
+  const int b = active ? tid : 0;
+#ifdef CRT_STAMP
+  double* stamp = const_cast<double*>(g.ws) + (long long)blockIdx.x * g.reclen;
+  int nstamp = 0;
+#define ZSTAMP() do { if (tid == 0 && nstamp < g.reclen) stamp[nstamp++] = (double)wall_clock64(); } while (0)
+#else
+#define ZSTAMP() do {} while (0)
+#endif
+  ZSTAMP();
+  S st;
+  st.init_band(rec, g, band);
+  if (active) bandc[b] = st.band_const();
+  const int K = Mg + 1;
+  const int seg_top = (K - 1) / M, k_top = seg_top * M;
+  double be[M], bf[M];
+  typename S::St fs;
+  st.first(rec, Mg, fs);
+  ZSTAMP();
+  tri_forward<S, M>(st, rec, Mg, fs, k_top, [&](int level, const typename S::St& cs) {
+    if (level < k_top) {
+      const int sidx = level / M - 1;
+      double e, f;
+      st.pair(cs, e, f);
+      ck[(2 * sidx) * nthr] = e;
+      ck[(2 * sidx + 1) * nthr] = f;
+    }
+  });
+  st.pair(fs, be[0], bf[0]);
+  if constexpr (M % S::RENORM != 0) st.seed(fs, be[0], bf[0]);
+#pragma unroll
+  for (int i = 1; i < M; ++i) {
+    be[i] = be[i - 1];
+    bf[i] = bf[i - 1];
+    if (k_top + i <= K - 1) tri_step(st, k_top + i - 1, rec, Mg, fs, be[i], bf[i]);
+  }
+  ZSTAMP();
+  // window of the last three computational rows (k, k + 1, k + 2): dnz[z] = SWd[z + 1], upz[z] = SWu[z]
+  double d0 = 0.0, d1 = 0.0, d2_ = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0;
+  int jn = nzo - 1;  // next output level to emit (they leave from the top)
+  int buf = 0;
+  auto pick = [](double x0, double x1, double x2, int i) { return i == 0 ? x0 : i == 1 ? x1 : x2; };
+  for (int seg = seg_top; seg >= 0; --seg) {
+    const int k0 = seg * M;
+    const int kend = min(k0 + M - 1, K - 1);
+    ZSTAMP();
+    if (seg != seg_top) {
+      typename S::St rs;
+      if (seg == 0) {
+        st.first(rec, Mg, rs);
+        st.pair(rs, be[0], bf[0]);
+      } else {
+        be[0] = ck[(2 * (seg - 1)) * nthr];
+        bf[0] = ck[(2 * (seg - 1) + 1) * nthr];
+        st.seed(rs, be[0], bf[0]);
+      }
+#pragma unroll
+      for (int i = 1; i < M; ++i) {
+        be[i] = be[i - 1];
+        bf[i] = bf[i - 1];
+        if (k0 + i <= kend) tri_step(st, k0 + i - 1, rec, Mg, rs, be[i], bf[i]);
+      }
+    }
+    ZSTAMP();
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+      const int k = k0 + i;
+      if (k <= kend) {
+        double o[S::NST];
+        if (k == K - 1) {
+          st.top(rec, Mg, be[i], bf[i], o);  // row Mg: boundary only, no output row
+        } else {
+          st.back(k, rec, Mg, be[i], bf[i], o);
+          d2_ = d1;
+          d1 = d0;
+          d0 = o[0];
+          u2 = u1;
+          u1 = u0;
+          u0 = o[1];
+          // every output level whose lowest row is k (wave-uniform: the level grid belongs to the column)
+          while (jn >= 0) {
+            const int ka = __builtin_amdgcn_readfirstlane((int)kidx[jn]);
+            if (max(ka - 2, 0) < k) break;  // (== k for any valid level grid; ">" cannot wait for a row that is already gone)
+            const double w = wgt[jn];
+            double da, db, ua, ub;
+            if (ka >= 2 && ka <= Mg - 1) {  // no clamp in play (every level but those next to the ground and the top): rows k + 1, k | k + 2, k + 1
+              da = d1;
+              db = d0;
+              ua = u2;
+              ub = u1;
+            } else {
+              da = pick(d0, d1, d2_, max(ka, 1) - 1 - k);      // SWd[ka]    (:310 clamp)
+              db = pick(d0, d1, d2_, max(ka - 1, 1) - 1 - k);  // SWd[ka-1]
+              ua = pick(u0, u1, u2, min(ka, Mg - 1) - k);      // SWu[ka]    (:335 clamp)
+              ub = pick(u0, u1, u2, min(ka - 1, Mg - 1) - k);  // SWu[ka-1]
+            }
+            const double dn = da + (db - da) * w;  // :360
+            const double up = ua + (ub - ua) * w;  // :361
+            if (active) {
+              double* tl = tile + buf * bstride + (jn % T) * nb + b;
+              tl[0] = dn;
+              tl[tstride] = up;
+            }
+            if (jn % T == 0) {  // output tile complete: hand it to the store waves
+              ZSTAMP();
+              lds_barrier();
+              if constexpr (RS > 0)
+                lds_barrier();
+              else
+                buf ^= 1;
+              ZSTAMP();
+            }
+            --jn;
+          }
+        }
+      }
+    }
+  }
+  // every hand-over the store waves count on has happened once jn < 0; a level grid that left levels behind (NaN in lai) still gets
+  // its barriers, so that no wave of the workgroup is left waiting
+  while (jn >= 0) {
+    if (jn % T == 0) {
+      lds_barrier();
+      if constexpr (RS > 0) lds_barrier();
+    }
+    --jn;
+  }
+}
+
+template <typename TIO, int M, int T, int MAXT, int RS>
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(M <= 8 ? 5 : 4))) void k_zqpa_pipe2(SolveArgs a, PipeCfg cfg) {
+  extern __shared__ double lds[];
+  TriBand band = {};
+  if ((int)threadIdx.x < cfg.ncomp) band = load_tri_band<TIO>(a, blockIdx.x, (int)threadIdx.x < a.nb ? threadIdx.x : 0);
+  {
+    const double* src = a.ws + (long long)blockIdx.x * a.reclen;
+    for (int i = threadIdx.x; i < a.reclen; i += blockDim.x) lds[i] = src[i];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x >= cfg.ncomp) {
+    // the store role of the other tridiagonal schemes on the caller's levels and output arrays
+    SolveArgs ao = a;
+    ao.nz = cfg.nz_out;
+    for (int i = 0; i < 4; ++i) ao.o[i] = cfg.out[i];
+    if constexpr (RS > 0)
+      tri_pipe_store_rs<ZqPaOut, TIO, M, T, RS>(ao, cfg, lds);
+    else
+      tri_pipe_store<ZqPaOut, TIO, M, T>(ao, cfg, lds);
+    return;
+  }
+  zqpa_compute<TIO, M, T, RS>(a, cfg, lds, band);
+}
+
+// returns CRT_ERR_UNSUPPORTED when the shape does not fit
+template <typename TIO, int M, int T, bool REGSTAGE>
+int launch_zqpa_fused2(const SolveArgs& a, hipStream_t s, int nsw, size_t lds_cap = MAX_WG_LDS) {
+  if (a.nb < (a.tune[12] > 0 ? a.tune[12] : 16) || a.nb % 2) return CRT_ERR_UNSUPPORTED;  // even nb: the fused (row, band pair) flush
+  for (int i = 0; i < 4; ++i)
+    if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) return CRT_ERR_UNSUPPORTED;
+  const int Mg = zqpa_M(a.nz);
+  const int ncomp = ((a.nb + 63) / 64) * 64;
+  if (nsw <= 0) nsw = ncomp <= 64 ? 1 : 3;
+  if (ncomp + 64 * nsw > 1024) nsw = (1024 - ncomp) / 64;
+  if (nsw < 1) return CRT_ERR_UNSUPPORTED;
+  if (REGSTAGE && T * (a.nb / 2) > PIPE_RS * 64 * nsw) return CRT_ERR_UNSUPPORTED;
+  const int nthr = ncomp + 64 * nsw;
+  SolveArgs g = a;  // computational-grid solve: nz := Mg; the outputs go through PipeCfg
+  g.nz = Mg;
+  for (int i = 0; i < 7; ++i) g.o[i] = nullptr;
+  PipeCfg cfg{};
+  cfg.ncomp = ncomp;
+  cfg.nck = std::max(Mg / M - 1, 0);
+  cfg.off_bc = (a.reclen + 1) & ~1;
+  cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
+  cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
+  cfg.nz_out = a.nz;
+  for (int i = 0; i < 4; ++i) cfg.out[i] = a.o[i];
+  const size_t sh = ((size_t)cfg.off_tile + (size_t)(REGSTAGE ? 1 : 2) * 2 * T * a.nb) * sizeof(double);
+  if (sh > lds_cap) return CRT_ERR_UNSUPPORTED;
+  auto go = [&](auto kern) {
+    if (sh > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+      return (int)CRT_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, g, cfg);
+    note_kernel("k_zqpa_pipe2<%s> %s M=%d T=%d store_waves=%d lds=%zu", sizeof(TIO) == 8 ? "f64" : "f32", REGSTAGE ? "register-staged" : "double-buffered",
+                M, T, nsw, sh);
+    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+  };
+  constexpr int RSV = REGSTAGE ? PIPE_RS : 0;
+  return nthr <= 512 ? go(k_zqpa_pipe2<TIO, M, T, 512, RSV>) : go(k_zqpa_pipe2<TIO, M, T, 1024, RSV>);
+}
+
 template <typename TIO, int M, int T, int MAXT, bool FLAT>
 __global__ __launch_bounds__(MAXT) void k_zqpa_pipe(SolveArgs a, PipeCfg cfg) {
   extern __shared__ double lds[];
@@ -345,6 +576,29 @@ int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s) {
       return st;  // f32 storage exists in the fused kernel only (the two-kernel path keeps its computational-grid scratch in fp64)
     }
     st = CRT_ERR_UNSUPPORTED;
+    // round 3: interpolation in the compute lanes + the plain fused store role (even nb; tune key 10 = 5 keeps the kernel below; key 10 = 6 /
+    // 7 force the double-buffered / register-staged form)
+    // Measured (tools/ragged_sweep.py, round 3; both kernels on the division-free sweep): 1e4 x 300 x 60 1.10 (below) vs 1.11-1.13 ms,
+    // 6000 x 300 x 100 1.23 vs 1.12-1.15, 3e4 x 106 x 60 1.23 vs 2.67, 1e5 x 38 x 100 3.00 vs 3.58 -> the new form above 128 bands only.
+    // Three workgroups per CU (M = 8 capped at 80 registers, 40 B of scratch) gave 1.19 ms: occupancy is not what binds it.
+    if (g_tri_tune[2] != 5 && (a.nb > 128 || g_tri_tune[2] >= 6 || g_tri_tune[0] == 8)) {
+      constexpr size_t HALF2 = MAX_WG_LDS / 2;
+      const int mode = g_tri_tune[2];
+      if (g_tri_tune[0] == 8) {  // A/B: short segments (fewer registers: five waves per SIMD, three workgroups per CU)
+        if (mode != 6) st = launch_zqpa_fused2<double, 8, 4, true>(a, s, nsw, MAX_WG_LDS / 3);
+        if (st == CRT_ERR_UNSUPPORTED && mode != 7) st = launch_zqpa_fused2<double, 8, 4, false>(a, s, nsw, MAX_WG_LDS / 3);
+        if (st == CRT_ERR_UNSUPPORTED) st = launch_zqpa_fused2<double, 8, 4, true>(a, s, nsw, HALF2);
+      } else if (a.nz <= 64) {  // few checkpoints: M = 16 keeps the LDS small; above, M = 16 as well (registers cap M)
+        if (mode != 6) st = launch_zqpa_fused2<double, 16, 4, true>(a, s, nsw, HALF2);
+        if (st == CRT_ERR_UNSUPPORTED && mode != 7) st = launch_zqpa_fused2<double, 16, 4, false>(a, s, nsw, HALF2);
+      } else {
+        if (mode != 6) st = launch_zqpa_fused2<double, 16, 4, true>(a, s, nsw, HALF2);
+        if (st == CRT_ERR_UNSUPPORTED && mode != 7) st = launch_zqpa_fused2<double, 16, 4, false>(a, s, nsw, HALF2);
+      }
+      if (st == CRT_ERR_UNSUPPORTED && mode != 6) st = launch_zqpa_fused2<double, 16, 4, true>(a, s, nsw);
+      if (st == CRT_ERR_UNSUPPORTED && mode != 7) st = launch_zqpa_fused2<double, 16, 4, false>(a, s, nsw);
+      if (st != CRT_ERR_UNSUPPORTED) return st;
+    }
     // narrow spectra (one compute wave per column): M = 12 needs 92 registers, five waves per SIMD instead of four (1e5 x 38 x 100:
     // 3.74 -> 3.64 ms, 2e5 x 16 x 60 3.23 -> 3.16; at 62 bands the other way, 2.61 -> 2.64).  (tune key 8 = 16 keeps M = 16.)
     if (a.nb <= 48 && g_tri_tune[0] != 16) st = launch_zqpa_fused<double, 12, 4>(a, s, nsw, HALF);

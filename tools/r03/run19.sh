@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out/r03
+O=gpurun_out/r03
+export CRT1D_HIP_LIB=$PWD/variants/libcrt1d_hip_stampz.so
+( timeout -k 10 120 python tools/stamp_timeline_tri.py zq_pa 10000 300 60 ) 2>&1 | grep -v amdgpu.ids > $O/stamps19.txt
+cat $O/stamps19.txt
