@@ -757,6 +757,8 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": load_pmc_traffic(kname, (ncol_kernel, nb_kernel, nz)),
+            "traffic_source": "lookup in profiles/pmc_traffic.json: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this command (same kernel family "
+                              "and launch shape, tools/profile_round.sh), NOT a counter of this run; null when that shape was not profiled",
             "algorithmic_bytes_per_launch": alg_bytes,
             "bytes_per_solve": bps,
             "launch_shape": [ncol_kernel, nb_kernel, nz],
@@ -766,11 +768,13 @@ def main():
             "kernel_ms_max": kt[-1],
             "kernel_ms_avg_torch_empty_outputs": k_ms_plain,
             "k0_ms": k0_ms,
-            "measured_fill_GBs": fill_gbs,  # linear fill of one 4 GiB buffer (one memory class at a time): a yardstick, not the ceiling
-            "measured_copy_GBs": copy_gbs,
-            "measured_store_set_GBs": store_set_gbs,  # the kernel's own flush pattern on the kernel's own output arrays
-            "frac_of_measured_fill": achieved / fill_gbs,
+            # the meaningful yardstick: the kernel's own flush pattern (no arithmetic) on the kernel's own output arrays
+            "measured_store_set_GBs": store_set_gbs,
             "frac_of_measured_store_set": (achieved / store_set_gbs) if store_set_gbs else None,
+            # reference points only, NOT ceilings: a linear fill writes one memory class at a time and is slower than the class-interleaved
+            # column pattern; a copy adds the read stream
+            "probe_linear_fill_GBs": fill_gbs,
+            "probe_copy_GBs": copy_gbs,
         }
 
     # ---- PCIe-inclusive step (N = 1, column partition): H2D of the per-band inputs + K0 + solve + D2H of every profile ----

@@ -1024,6 +1024,20 @@ static int solve_impl(int scheme, const crt_columns* cols, const crt_bands* band
     flags = opts->flags;
     for (int i = 0; i < CRT_NTUNE; ++i) tune[i] = opts->tune[i];
   }
+  {  // crt_options.tune is a measurement aid, but it is part of the ABI: out-of-range values are rejected here, before any launch,
+     // instead of reaching the kernel configurations (keys: crt_internal.hpp, SolveArgs::tune)
+    static const struct { int key, lo, hi; } range[] = {
+        {0, 0, 160 * 1024}, {1, 0, 64}, {2, 0, 255}, {3, 0, 12}, {4, 0, 32}, {8, 0, 16}, {9, 0, 12}, {10, 0, 7}, {11, 0, 12}, {12, 0, 1024}, {13, 0, 1}};
+    bool known[CRT_NTUNE] = {};
+    for (const auto& r : range) {
+      known[r.key] = true;
+      if (tune[r.key] < r.lo || tune[r.key] > r.hi) return CRT_ERR_BAD_ARG;
+    }
+    if (tune[8] != 0 && tune[8] != 8 && tune[8] != 12 && tune[8] != 16) return CRT_ERR_BAD_ARG;
+    if (tune[9] != 0 && tune[9] != 4 && tune[9] != 8 && tune[9] != 12) return CRT_ERR_BAD_ARG;
+    for (int i = 0; i < CRT_NTUNE; ++i)
+      if (!known[i] && tune[i] != 0) return CRT_ERR_BAD_ARG;  // reserved keys stay zero
+  }
   if (scheme == CRT_SCHEME_4S && !(mu_s > 0.0 && mu_s < 1.0)) return CRT_ERR_BAD_ARG;
   if (method != CRT_TAU_D_QUAD && method != CRT_TAU_D_9SKY) return CRT_ERR_BAD_ARG;  // ValueError, common.py:78
   const size_t need = crt_hip_workspace_bytes_nb(scheme, ncol, nz, nb);

@@ -9,9 +9,9 @@
 // arbitrary Python callables.  On device the integrals use FIXED nodes:
 //   * tau_d(L) = 2 int_0^{pi/2} exp(-K_b(psi) L) sin cos dpsi   (common.py:30-37)
 //     mu_bar   =   int_0^{pi/2} cos sin / G(psi) dpsi           (_solve_2s.py:32)
-//       6 panels x 16-point Gauss-Legendre on psi in [0, pi/2], panel widths shrinking by 4x toward
-//       pi/2 where exp(-G L / cos psi) has its essential singularity: <= 3e-13 relative for
-//       L in [1e-3, 20] and every leaf-angle class (the reference's own quad error is up to ~3e-8).
+//       6 panels x 16-point Gauss-Legendre on psi in [0, pi/2], panel edges at decades of pi/2 - psi toward
+//       pi/2 where exp(-G L / cos psi) has its essential singularity: 1 - tau_d <= 2.3e-12 relative for
+//       L in [3e-4, 20], mu_bar <= 3e-13 (the reference's own quad error is up to ~3e-8 in tau_d).
 //   * G_int_1 = int_0^{mu_s} G(acos m) dm,  G_int_2 = int_{mu_s}^1   (_solve_4s.py:148-149)
 //       16-point Gauss-Legendre each, in psi (dm = -sin psi dpsi).
 //   * '9sky': the reference's own 9 fixed angles                 (common.py:40-53)
@@ -30,7 +30,13 @@ constexpr int NQT = CRT_NQ_TAU;
 constexpr int NQG = CRT_NQ_G4;
 constexpr int NPAN = 6;
 constexpr int NGL = 16;
-constexpr double PAN_RATIO = 0.25;
+// Panel edges in t = pi/2 - psi, as fractions of pi/2: decades towards psi = pi/2, where e^{-G L / cos psi} has its boundary layer (at
+// cos psi ~ G L), and a split of the wide end, where 1/G of an ellipsoidal distribution with small x has its own structure at psi -> 0
+// (mu_bar).  Chosen by a scan over edge sets against 30-digit quadrature, ellipsoidal-approx G with x in {0.2, 0.3, 0.96, 3}
+// (DESIGN 3.2): 1 - tau_d(L) <= 2.3e-12 relative for every L in [3e-4, 20] (1.3e-10 at 1e-4), mu_bar <= 3e-13.  The geometric 4x grading
+// of rounds 1-2 gave 1e-8 at L = 3e-4 -- n79 divides 1 - tau_d(dlai) by dlai, and its per-leaf-area absorption on fine ragged grids was
+// the one output that saw it -- and 8e-10 in mu_bar at x = 0.2.
+constexpr double PAN_EDGE[NPAN + 1] = {0.0, 1e-4, 1e-3, 1e-2, 0.1, 0.6, 1.0};
 static_assert(NPAN * NGL == NQT, "tau_d rule size");
 static_assert(2 * NGL == NQG, "4s rule size");
 
@@ -74,10 +80,9 @@ void gauss_legendre(int n, double* x, double* w) {
 void build_host_tables() {
   gauss_legendre(NGL, h_qc.gx, h_qc.gw);
   const double T = M_PI / 2;
-  // panel edges in t = pi/2 - psi: 0, T r^(NPAN-1), ..., T r, T
+  // panel edges in t = pi/2 - psi
   double edge[NPAN + 1];
-  edge[0] = 0.0;
-  for (int k = 1; k <= NPAN; ++k) edge[k] = T * pow(PAN_RATIO, NPAN - k);
+  for (int k = 0; k <= NPAN; ++k) edge[k] = T * PAN_EDGE[k];
   int q = 0;
   for (int k = 0; k < NPAN; ++k) {
     const double a = edge[k], b = edge[k + 1];
@@ -120,6 +125,15 @@ static_assert(K0_BLOCK == 8 * BL_CHUNK && CRT_NQ_TAU % 8 == 0, "bl chunk reducti
 __device__ inline double tau_d_quad(const double* kq, double L) {
   double s = 0.0;
   for (int q = 0; q < NQT; ++q) s += qc.w2sc[q] * fexp(-kq[q] * L);
+  return s;
+}
+
+// 1 - tau_d(L) = 2 int (1 - e^{-K_b(psi) L}) sin cos dpsi  (the weights 2 w sin cos integrate to one): every term by expm1, so that the
+// result keeps its RELATIVE accuracy at small L, where tau_d -> 1.  n79 divides (1 - tau_d(dlai)) by dlai afterwards (_solve_n79.py:146,
+// 154-155): formed as 1 - tau_d the ~3e-13 by which two quadrature rules differ in tau_d became ~2e-8 at dlai ~ 3e-4 (round 2).
+__device__ inline double one_minus_tau_d_quad(const double* kq, double L) {
+  double s = 0.0;
+  for (int q = 0; q < NQT; ++q) s -= qc.w2sc[q] * fexpm1(-kq[q] * L);
   return s;
 }
 
@@ -278,10 +292,12 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
   const bool n79u = a.scheme == CRT_SCHEME_N79 && sh_unif != 0 && nz >= 3;
   if (n79u) {
     const double dl = sh_dl;
+    // (sh_tdu holds 1 - tau_d: see one_minus_tau_d_quad; '9sky' has no such form -- its nine weights do not sum to one -- and is 1 - tau_d
+    //  as the reference computes it)
     if (a.tau_d_method == CRT_TAU_D_9SKY) {
-      if (tid == 0) sh_tdu = tau_d_9sky(k9, dl);
+      if (tid == 0) sh_tdu = 1.0 - tau_d_9sky(k9, dl);
     } else {
-      for (int q = tid; q < NQT; q += K0_BLOCK) pmb[q] = qc.w2sc[q] * fexp(-kq[q] * dl);
+      for (int q = tid; q < NQT; q += K0_BLOCK) pmb[q] = -qc.w2sc[q] * fexpm1(-kq[q] * dl);
       __syncthreads();
       if (wave == 0) {
         const double t = wave_sum64(pmb[lane] + (lane < NQT - 64 ? pmb[64 + lane] : 0.0));
@@ -361,29 +377,29 @@ __global__ __launch_bounds__(K0_BLOCK) void k_colpre(ColArgs a) {
         break;
       case CRT_SCHEME_N79: {
         v[j] = ekl;  // tbcum  _solve_n79.py:46
-        double tb = 0, td = 0, fs = 0, isl = 0, ish = 0;
+        double omtb = 1, omtd = 1, fs = 0, isl = 0, ish = 0;  // 1 - tb, 1 - td
         if (j + 1 < nz) {
           const double Ln = lai[j + 1];
           const double dl = L - Ln;                                             // :40
           if (n79u) {
-            tb = fexp(-Kb * sh_dl);
-            td = sh_tdu;
+            omtb = -fexpm1(-Kb * sh_dl);
+            omtd = sh_tdu;
           } else {
-            tb = fexp(-Kb * dl);                                                 // :45
-            td = (a.tau_d_method == CRT_TAU_D_9SKY) ? tau_d_9sky(k9, dl) : tau_d_quad(kq, dl);  // :53
+            omtb = -fexpm1(-Kb * dl);                                            // 1 - tb, :45
+            omtd = (a.tau_d_method == CRT_TAU_D_9SKY) ? 1.0 - tau_d_9sky(k9, dl) : one_minus_tau_d_quad(kq, dl);  // 1 - td, :53
           }
           fs = fexp(-Kb * ((L + Ln) / 2));                                       // :57-58
           isl = 1.0 / (fs * dl);                                                // :154
           ish = 1.0 / ((1.0 - fs) * dl);                                        // :155
         }
-        // what the level loops multiply by, formed once per column (tri_schemes.hpp, TriN79): 1 - tb, fs / (fs dlai), 1 / (fs dlai),
-        // (1 - fs) / ((1 - fs) dlai)
-        v[nz + j] = 1.0 - tb;
-        v[2 * nz + j] = td;
+        // what the level loops multiply by, formed once per column (tri_schemes.hpp, TriN79): 1 - tb, 1 - td, fs / (fs dlai), 1 / (fs dlai),
+        // (1 - fs) / ((1 - fs) dlai), 1 / (1 - td)
+        v[nz + j] = omtb;
+        v[2 * nz + j] = omtd;
         v[3 * nz + j] = fs * isl;
         v[4 * nz + j] = isl;
         v[5 * nz + j] = (1.0 - fs) * ish;
-        v[6 * nz + j] = 1.0 / (1.0 - td);  // refld = (1 - td) rho  ->  1/refld = (1/rho) * this
+        v[6 * nz + j] = 1.0 / omtd;  // refld = (1 - td) rho  ->  1/refld = (1/rho) * this
         break;
       }
       default:  // 2s, 4s, g77, bf

@@ -15,7 +15,7 @@ namespace crt {
 //   vectors (by scheme):
 //     2s, 4s, g77, bf : lai, ekl = exp(-K_b lai)
 //     bl              : lai, ekl, tau_d(lai_j)                       (_solve_bl.py:31-37)
-//     n79             : tbcum = ekl, 1 - tb, td, fracsun/(fracsun dlai), 1/(fracsun dlai), fracsha/(fracsha dlai), 1/(1 - td)
+//     n79             : tbcum = ekl, 1 - tb, 1 - td, fracsun/(fracsun dlai), 1/(fracsun dlai), fracsha/(fracsha dlai), 1/(1 - td)
 //                                                                     (_solve_n79.py:40-59)
 //     zq              : ekl                                           (_solve_zq.py:130)
 //     zq_pa           : beam fraction on the M computational layers, ekl, interpolation index, weight
@@ -80,10 +80,14 @@ struct SolveArgs {
   void* o[7];  // I_dr, I_df_d, I_df_u, F, x0, x1, x2
   double mu_s;
   int f32;     // 0: TIO = double, 1: TIO = float
-  // kernel-selection overrides of THIS call (crt_options.tune; 0 = automatic): [0] LDS bytes a closed-form tile may take,
-  // [1] force T of k_tile, [2] flags (bit0 __syncthreads barriers, bit1 generic flush, bit2 no pipeline, bit3 no generic-flush
-  // pipeline), [3] store waves of k_pipe, [4] T of k_pipe; [8] M, [9] T, [10] kernel family, [11] store waves of the tridiagonal
-  // kernels (tri_tile_impl.hpp); [12] smallest nb that takes the tile / pipeline kernels (0 = default)
+  // kernel-selection overrides of THIS call (crt_options.tune; 0 = automatic; validated by solve_impl, api.hip: out-of-range values and
+  // non-zero reserved keys are CRT_ERR_BAD_ARG): [0] LDS bytes a closed-form tile may take (<= 160 KB), [1] force T of k_tile (<= 64),
+  // [2] flags (bit0 __syncthreads barriers, bit1 generic flush, bit2 no pipeline, bit3 no generic-flush pipeline, value 16: four-pair
+  // store role for narrow tridiagonal pipelines), [3] store waves of k_pipe (<= 12), [4] T of k_pipe (<= 32); [8] M (8 / 12 / 16),
+  // [9] T (4 / 8 / 12), [10] kernel family of the tridiagonal kernels (1 no pipeline, 2 double-buffered, 3 register-staged, 4 generic
+  // pipeline; zq_pa: 1 two-kernel path, 5 round-2 fused kernel, 6 / 7 double-buffered / register-staged k_zqpa_pipe2), [11] their store
+  // waves (<= 12) (tri_tile_impl.hpp, tri_zqpa.hip); [12] smallest nb that takes the tile / pipeline kernels (0 = default);
+  // [13] 1 = no flat fused flush for odd nb (per-array generic flush instead); [5..7], [14], [15] reserved (zero)
   int tune[CRT_NTUNE];
 };
 
@@ -264,6 +268,23 @@ __device__ __forceinline__ double fexp(double x) {
   q = __builtin_fma(q, r, 1.0);
   q = __builtin_fma(q, r, 1.0);
   return __builtin_ldexp(q, (int)k);
+}
+
+// e^x - 1 without the cancellation of fexp(x) - 1 at small |x|: inside the reduced range (|x| <= ln2 / 2, k = 0) e^x - 1 = x + x^2 q(x) with the
+// SAME polynomial q as fexp -- relative error ~1e-16 down to x -> 0 -- and fexp(x) - 1 beyond, where e^x is <= 0.71 or >= 1.41.
+// Used where a quantity of the form 1 - e^{-k L} is divided by L afterwards (n79's per-leaf-area absorption at small dlai).
+__device__ __forceinline__ double fexpm1(double x) {
+  if (__builtin_fabs(x) > 0.34657359027997264) return fexp(x) - 1.0;
+  double q = fma_vvs(x, 0x1.af389ecfc4b9cp-26, 0x1.28917c89a43a7p-22);
+  q = fma_vvs(q, x, 0x1.71de0db2f6b19p-19);
+  q = fma_vvs(q, x, 0x1.a019b9149a41cp-16);
+  q = fma_vvs(q, x, 0x1.a01a01a7c2efep-13);
+  q = fma_vvs(q, x, 0x1.6c16c17889ef1p-10);
+  q = fma_vvs(q, x, 0x1.11111111109b5p-7);
+  q = fma_vvs(q, x, 0x1.5555555553d68p-5);
+  q = fma_vvs(q, x, 0x1.5555555555556p-3);
+  q = fma_vvs(q, x, 0x1.0000000000001p-1);
+  return __builtin_fma(x * x, q, x);
 }
 
 // sin and cos of a moderate argument (|th| < ~1e6) in ~35 instructions: two-term Cody-Waite reduction by pi/2 (the first product is

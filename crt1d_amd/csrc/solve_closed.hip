@@ -928,8 +928,9 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh) != hipSuccess)
           return (int)CRT_ERR_LAUNCH;
         hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(pthr), psh, s, a, pc);
-        note_kernel("k_pipe<%s,%s>%s T=%d store_waves=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", fused ? "" : " generic-flush", Tp, nsw, psh);
-        return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+        if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
+        note_kernel("k_pipe<%s,%s>%s T=%d store_waves=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", fused ? "" : " generic-flush", Tp, nsw, psh);  // (only a launch that succeeded is reported)
+        return (int)CRT_OK;
       };
       int st;
       if (fused) st = pthr <= 512 ? gop(k_pipe<S, TIO, 512, true>) : gop(k_pipe<S, TIO, 1024, true>);
@@ -943,8 +944,9 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nthr), sh, s, a, cfg);
-    note_kernel("k_tile<%s,%s>%s CB=%d T=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", fused ? "" : " generic-flush", CB, T, sh);
-    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+    if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
+    note_kernel("k_tile<%s,%s>%s CB=%d T=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", fused ? "" : " generic-flush", CB, T, sh);  // (only a launch that succeeded is reported)
+    return (int)CRT_OK;
   };
   int st;
   if (fused) {
@@ -966,8 +968,9 @@ int launch_direct_v(const SolveArgs& a, size_t lds_bytes, hipStream_t s) {
   const long long nblk = (items + DBLOCK - 1) / DBLOCK;
   if (nblk > 0x7fffffffLL) return CRT_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((k_direct<S, TIO, VEC, USE_LDS>), dim3((unsigned)nblk), dim3(DBLOCK), USE_LDS ? lds_bytes : 0, s, a);
-  note_kernel("k_direct<%s,%s> VEC=%d", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", VEC);
-  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+  if (hipGetLastError() != hipSuccess) return CRT_ERR_LAUNCH;
+  note_kernel("k_direct<%s,%s> VEC=%d", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", VEC);  // (only a launch that succeeded is reported)
+  return CRT_OK;
 }
 
 template <class S, typename TIO>
@@ -1052,8 +1055,9 @@ int launch_int(const SolveArgs& a, const IntArgs& ia, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, ia, rec_dbl);
-    note_kernel("k_int<%s>%s", S::NAME, prof ? " + level profiles" : " wave totals");
-    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+    if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
+    note_kernel("k_int<%s>%s", S::NAME, prof ? " + level profiles" : " wave totals");  // (only a launch that succeeded is reported)
+    return (int)CRT_OK;
   };
   if (prof) {
     if (nthr <= 256) return go(k_int<S, TIO, 256, true>);

@@ -174,8 +174,9 @@ int launch_wave(const SolveArgs& a, hipStream_t s) {
     const int st = set_lds_limit(kern, sh);
     if (st != CRT_OK) return st;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(TB), sh, s, a, (int)rec_doubles);
-    note_kernel("k_tri_wave<%s,%s> pairs in %s", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", ef_in_lds ? "LDS" : "output rows");
-    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+    if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
+    note_kernel("k_tri_wave<%s,%s> pairs in %s", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", ef_in_lds ? "LDS" : "output rows");  // (only a launch that succeeded is reported)
+    return (int)CRT_OK;
   };
   if (ef_in_lds) return use_lds ? go(k_tri_wave<S, TIO, true, EfLds>) : go(k_tri_wave<S, TIO, false, EfLds>);
   return use_lds ? go(k_tri_wave<S, TIO, true, EfOut<TIO>>) : go(k_tri_wave<S, TIO, false, EfOut<TIO>>);

@@ -126,14 +126,14 @@ struct TriN79 {
     irho = fast_rcp(rho);
     invmu = rec[S_INVMU];
   }
-  // K0 vectors of the record (colpre.hip): [0] tbcum = e^{-K_b lai}, [1] 1 - tb, [2] td, [3] fs / (fs dlai), [4] 1 / (fs dlai),
+  // K0 vectors of the record (colpre.hip): [0] tbcum = e^{-K_b lai}, [1] 1 - tb, [2] 1 - td (by expm1), [3] fs / (fs dlai), [4] 1 / (fs dlai),
   // [5] (1 - fs) / ((1 - fs) dlai), [6] 1 / (1 - td).  Explicit FMAs throughout (the build runs with -ffp-contract=off): the sweeps are
   // dependency chains, every fused pair is one step less on them.
   // layer scattering coefficients (:85-88 / :102-105): r = trand/refld, s = refld - trand^2/refld.
   // 1/refld = (1/rho) * 1/(1 - td_j): a per-band register times a per-level K0 vector, no division here.
   __device__ inline void layer(const double* rec, int nz, int j, double& r, double& s) const {
-    const double t = rec[REC_HDR + 2 * nz + j];
-    const double omt = 1 - t;
+    const double omt = rec[REC_HDR + 2 * nz + j];
+    const double t = 1 - omt;
     const double refld = omt * rho;
     const double trand = __builtin_fma(omt, tau, t);
     r = trand * (irho * rec[REC_HDR + 6 * nz + j]);
@@ -179,8 +179,8 @@ struct TriN79 {
   // level k from level k+1; emits output level k and layer k
   __device__ inline void back(int k, const double* rec, int nz, double e, double f, double (&o)[NST]) {
     const double* tbcum = rec + REC_HDR;
-    const double t = rec[REC_HDR + 2 * nz + k];
-    const double omt = 1 - t;
+    const double omt = rec[REC_HDR + 2 * nz + k];
+    const double t = 1 - omt;
     const double refld = omt * rho;
     const double trand = __builtin_fma(omt, tau, t);
     const double src = swb * tbcum[k + 1] * rec[REC_HDR + nz + k];
@@ -240,16 +240,16 @@ struct TriN79U : TriN79 {
     const int nz = a.nz;
     layer(rec, nz, 1, r, s);
     rr = r * r;
-    const double t = rec[REC_HDR + 2 * nz + 1];
+    const double omt = rec[REC_HDR + 2 * nz + 1], t = 1 - omt;
     omtb = rec[REC_HDR + nz + 1];
     k_odd = omtb * __builtin_fma(-rho, r, tau);   // (:92, :119)
     k_even = omtb * __builtin_fma(-tau, r, rho);  // (:109, :129)
-    refld = (1 - t) * rho;
-    const double trand = __builtin_fma(1 - t, tau, t);
+    refld = omt * rho;
+    const double trand = __builtin_fma(omt, tau, t);
     itrand = fast_rcp(trand);
     k_dn = __builtin_fma(trand, trand, -(refld * refld));
     k_src = omtb * __builtin_fma(rho, refld, -(tau * trand));
-    omt_oma = (1 - t) * oma;
+    omt_oma = omt * oma;
   }
   __device__ inline void advance(int k, const double* rec, int nz, double& e, double& f) const {
     const double src = swb * rec[REC_HDR + k + 1];

@@ -374,8 +374,9 @@ int launch_mt(const SolveArgs& a, hipStream_t s, int nthr) {
     hipLaunchKernelGGL((k_tri_tile<S, TIO, M, T, 512, FUSED>), grid, block, sh, s, a, cfg);
   else
     hipLaunchKernelGGL((k_tri_tile<S, TIO, M, T, 1024, FUSED>), grid, block, sh, s, a, cfg);
-  note_kernel("k_tri_tile<%s,%s>%s M=%d T=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", FUSED ? "" : cfg.flat ? " flat-flush" : " generic-flush", M, T, sh);
-  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+  if (hipGetLastError() != hipSuccess) return CRT_ERR_LAUNCH;
+  note_kernel("k_tri_tile<%s,%s>%s M=%d T=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", FUSED ? "" : cfg.flat ? " flat-flush" : " generic-flush", M, T, sh);  // (only a launch that succeeded is reported)
+  return CRT_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -488,8 +489,9 @@ int launch_int_m(const SolveArgs& a, const IntArgs& ia, hipStream_t s, int nthr)
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, ia, off_ck, off_int);
-    note_kernel("k_tri_int<%s> M=%d%s", S::NAME, M, prof ? " + level profiles" : "");
-    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+    if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
+    note_kernel("k_tri_int<%s> M=%d%s", S::NAME, M, prof ? " + level profiles" : "");  // (only a launch that succeeded is reported)
+    return (int)CRT_OK;
   };
   if (prof) {
     if (nthr <= 256) return go(k_tri_int<S, TIO, M, 256, true>);
@@ -863,9 +865,10 @@ int launch_pipe_generic(const SolveArgs& a, hipStream_t s, int nstore_waves) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
     return CRT_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, cfg);
+  if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
   note_kernel("k_tri_pipe<%s,%s> %s M=%d T=%d store_waves=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", cfg.flat ? "flat-flush" : "generic-flush", M, T,
-              nstore_waves, sh);
-  return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+              nstore_waves, sh);  // (only a launch that succeeded is reported)
+  return (int)CRT_OK;
 }
 
 template <class S, typename TIO, int M, int T>
@@ -890,9 +893,10 @@ int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves, bool reg
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, cfg);
+    if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
     note_kernel("k_tri_pipe<%s,%s> %s M=%d T=%d store_waves=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32",
-                regstage ? (narrow_rs ? "register-staged(2 pairs)" : "register-staged") : "double-buffered", M, T, nstore_waves, sh);
-    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+                regstage ? (narrow_rs ? "register-staged(2 pairs)" : "register-staged") : "double-buffered", M, T, nstore_waves, sh);  // (only a launch that succeeded is reported)
+    return (int)CRT_OK;
   };
   if constexpr (T == 4 && M == 8) {  // narrow spectra: two staged pairs per store thread cover the tile
     if (narrow_rs) return go(k_tri_pipe<S, TIO, M, T, 512, 2>);  // (crt_options.tune[2] = 16 keeps the four-pair form: A/B)

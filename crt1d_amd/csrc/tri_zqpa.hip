@@ -486,9 +486,10 @@ int launch_zqpa_fused2(const SolveArgs& a, hipStream_t s, int nsw, size_t lds_ca
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, g, cfg);
+    if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
     note_kernel("k_zqpa_pipe2<%s> %s M=%d T=%d store_waves=%d lds=%zu", sizeof(TIO) == 8 ? "f64" : "f32", REGSTAGE ? "register-staged" : "double-buffered",
-                M, T, nsw, sh);
-    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+                M, T, nsw, sh);  // (only a launch that succeeded is reported)
+    return (int)CRT_OK;
   };
   constexpr int RSV = REGSTAGE ? PIPE_RS : 0;
   return nthr <= 512 ? go(k_zqpa_pipe2<TIO, M, T, 512, RSV>) : go(k_zqpa_pipe2<TIO, M, T, 1024, RSV>);
@@ -551,8 +552,9 @@ int launch_zqpa_fused(const SolveArgs& a, hipStream_t s, int nsw, size_t lds_cap
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return (int)CRT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, g, cfg);
-    note_kernel("k_zqpa_pipe<%s%s> M=%d T=%d store_waves=%d lds=%zu", sizeof(TIO) == 8 ? "f64" : "f32", flat ? ",flat" : "", M, T, nsw, sh);
-    return hipGetLastError() == hipSuccess ? (int)CRT_OK : (int)CRT_ERR_LAUNCH;
+    if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
+    note_kernel("k_zqpa_pipe<%s%s> M=%d T=%d store_waves=%d lds=%zu", sizeof(TIO) == 8 ? "f64" : "f32", flat ? ",flat" : "", M, T, nsw, sh);  // (only a launch that succeeded is reported)
+    return (int)CRT_OK;
   };
   if (flat) return nthr <= 512 ? go(k_zqpa_pipe<TIO, M, T, 512, true>) : go(k_zqpa_pipe<TIO, M, T, 1024, true>);
   return nthr <= 512 ? go(k_zqpa_pipe<TIO, M, T, 512, false>) : go(k_zqpa_pipe<TIO, M, T, 1024, false>);
@@ -636,8 +638,9 @@ int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
     return CRT_ERR_LAUNCH;
   hipLaunchKernelGGL((k_zqpa_interp<double>), dim3(a.ncol), dim3(256), sh, s, ia);
-  note_kernel("zq_pa two-kernel path: grid solve + k_zqpa_interp");
-  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_LAUNCH;
+  if (hipGetLastError() != hipSuccess) return CRT_ERR_LAUNCH;
+  note_kernel("zq_pa two-kernel path: grid solve + k_zqpa_interp");  // (only a launch that succeeded is reported)
+  return CRT_OK;
 }
 
 }  // namespace crt

@@ -171,8 +171,15 @@ class BandShardPlan:
         return sum(t.flat.numel() * 8 for t in self.tiles)
 
     def __call__(self, reduce=True):
-        """Enqueue one step.  ``reduce=False`` skips the collectives (compute-only timing)."""
+        """Enqueue one step.  ``reduce=False`` skips the collectives (compute-only timing).
+
+        A step whose collectives have not been completed (no :meth:`wait` since the last call) is completed first: the epilogue of this
+        step writes into the very message buffers (``tile.flat``) the previous step's asynchronous all-reduce may still be reading on the
+        RCCL stream."""
         for tile in self.tiles:
+            if tile.work is not None:
+                tile.work.wait()  # stream-ordered for RCCL: the host does not block, the compute stream waits for the collective
+                tile.work = None
             tile.profiles = tile.launch()
             tile.work = None
             tile.reduced = False

@@ -112,13 +112,16 @@ class Columns:
 # quadrature (replaces QUADPACK)
 
 
-def _graded_rule(npan=8, n=20, ratio=0.3):
-    """Composite GL on psi in [0, pi/2], panels shrinking geometrically toward pi/2."""
+def _graded_rule(n=24, edges=(0.0, 3e-5, 3e-4, 3e-3, 0.03, 0.2, 0.45, 0.7, 1.0)):
+    """Composite Gauss-Legendre on psi in [0, pi/2]: panels (edges in t = pi/2 - psi, fractions of pi/2) graded toward pi/2, where
+    e^{-G L / cos psi} has its boundary layer, and split at the wide end for 1/G of small-x ellipsoidal distributions.  8 x 24 nodes:
+    1 - tau_d(L) and mu_bar to <= 3e-15 relative for L in [1e-4, 20], x in [0.2, 3] against 30-digit quadrature -- deliberately a different
+    and finer rule than the device's 6 x 16 (csrc/colpre.hip), so that HIP-vs-oracle parity also checks the device's quadrature."""
     x, w = leggauss(n)
     T = PI / 2
-    edges = [0.0] + [T * ratio**k for k in range(npan - 1, -1, -1)]  # in t = pi/2 - psi
+    e = [T * f for f in edges]
     ps, ws = [], []
-    for a, b in zip(edges[:-1], edges[1:]):
+    for a, b in zip(e[:-1], e[1:]):
         t = a + (x + 1) * (b - a) / 2
         ps.append(T - t)
         ws.append(w * (b - a) / 2)
@@ -154,6 +157,22 @@ def tau_d(cols, L, *, method="quad", exact_quad=False):
             continue
         k = cols.G(c, psis) / np.cos(psis)  # (nq,)
         out[c] = np.exp(-np.outer(L[c], k)) @ wts
+    return out
+
+
+def one_minus_tau_d(cols, L, *, method="quad", exact_quad=False):
+    """1 - tau_d(L).  For the fixed-node rule it is integrated directly, 2 int (1 - e^{-K_b L}) sin cos dpsi with expm1 (the weights
+    integrate to one), which keeps its RELATIVE accuracy as L -> 0; n79 divides it by dlai (_solve_n79.py:146,154-155), and formed as
+    1 - tau_d the ~3e-13 by which two quadrature rules differ in tau_d became ~2e-8 at dlai ~ 3e-4.  '9sky' and the reference's own
+    adaptive quadrature (exact_quad) stay 1 - tau_d, as the reference computes it (_solve_n79.py:99,146)."""
+    L = np.asarray(L, dtype=np.float64)
+    if method != "quad" or exact_quad:
+        return 1 - tau_d(cols, L, method=method, exact_quad=exact_quad)
+    wts = 2 * _W_Q * np.sin(_PSI_Q) * np.cos(_PSI_Q)
+    out = np.empty_like(L)
+    for c in range(cols.ncol):
+        k = cols.G(c, _PSI_Q) / np.cos(_PSI_Q)
+        out[c] = -np.expm1(-np.outer(L[c], k)) @ wts
     return out
 
 
@@ -371,7 +390,11 @@ def solve_n79(cols, *, I_dr0, I_df0, leaf_r, leaf_t, soil_r, tau_d_method="quad"
     dlai = lai[:, :-1] - lai[:, 1:]  # :40
     tb = np.exp(-K_b[:, None] * dlai)  # :45
     tbcum = np.exp(-K_b[:, None] * lai)  # :46
-    td = tau_d(cols, dlai, method=tau_d_method, exact_quad=exact_quad)  # :53
+    if tau_d_method not in ("quad", "9sky"):
+        raise ValueError("invalid `method`. Valid options are 'quad' and '9sky'.")
+    omtd = one_minus_tau_d(cols, dlai, method=tau_d_method, exact_quad=exact_quad)  # 1 - td, :53
+    td = 1 - omtd
+    omtb = -np.expm1(-K_b[:, None] * dlai) if not exact_quad else 1 - tb  # 1 - tb
     laim = (lai[:, :-1] + lai[:, 1:]) / 2  # :57
     fsun = np.exp(-K_b[:, None] * laim)  # :58
     fsha = 1 - fsun
@@ -390,9 +413,9 @@ def solve_n79(cols, *, I_dr0, I_df0, leaf_r, leaf_t, soil_r, tau_d_method="quad"
     d = np.zeros((n, nc, nb))
 
     def layer(j):  # scattering coefficients of layer j (uses td[j])
-        t = td[:, j][:, None]
-        refld = (1 - t) * rho
-        trand = (1 - t) * tau + t
+        t, omt = td[:, j][:, None], omtd[:, j][:, None]
+        refld = omt * rho
+        trand = omt * tau + t
         return refld - trand * trand / refld, trand / refld
 
     # soil, upward (:79-82)
@@ -401,18 +424,18 @@ def solve_n79(cols, *, I_dr0, I_df0, leaf_r, leaf_t, soil_r, tau_d_method="quad"
     # first downward row uses index **1** of td/tb/tbcum (:85-92)
     aiv, biv = layer(1)
     a[1], c[1] = -aiv, -biv
-    d[1] = swb * tbcum[:, 1][:, None] * (1 - tb[:, 1][:, None]) * (tau - rho * biv)
+    d[1] = swb * tbcum[:, 1][:, None] * omtb[:, 1][:, None] * (tau - rho * biv)
     for j in range(nz - 2):  # :95-119
         ju, jd = 2 * (j + 1), 2 * (j + 1) + 1
         fiv, eiv = layer(j)
         a[ju], c[ju] = -eiv, -fiv
-        d[ju] = swb * tbcum[:, j + 1][:, None] * (1 - tb[:, j][:, None]) * (rho - tau * eiv)
+        d[ju] = swb * tbcum[:, j + 1][:, None] * omtb[:, j][:, None] * (rho - tau * eiv)
         aiv, biv = layer(j + 1)
         a[jd], c[jd] = -aiv, -biv
-        d[jd] = swb * tbcum[:, j + 2][:, None] * (1 - tb[:, j + 1][:, None]) * (tau - rho * biv)
+        d[jd] = swb * tbcum[:, j + 2][:, None] * omtb[:, j + 1][:, None] * (tau - rho * biv)
     fiv, eiv = layer(nz - 2)  # top layer upward: td[-1] (:122-129)
     a[n - 2], c[n - 2] = -eiv, -fiv
-    d[n - 2] = swb * tbcum[:, -1][:, None] * (1 - tb[:, -1][:, None]) * (rho - tau * eiv)
+    d[n - 2] = swb * tbcum[:, -1][:, None] * omtb[:, -1][:, None] * (rho - tau * eiv)
     d[n - 1] = swd  # :132-135
 
     u = _thomas(a, b, c, d)  # :138
@@ -420,8 +443,8 @@ def solve_n79(cols, *, I_dr0, I_df0, leaf_r, leaf_t, soil_r, tau_d_method="quad"
     swdn = np.moveaxis(u[1::2], 0, 1)  # :142
 
     om = (rho + tau)[:, None, :]
-    direct = swb[:, None, :] * tbcum[:, 1:, None] * (1 - tb[:, :, None]) * (1 - om)  # :145
-    diffuse = (swdn[:, 1:] + swup[:, :-1]) * (1 - td[:, :, None]) * (1 - om)  # :146
+    direct = swb[:, None, :] * tbcum[:, 1:, None] * omtb[:, :, None] * (1 - om)  # :145
+    diffuse = (swdn[:, 1:] + swup[:, :-1]) * omtd[:, :, None] * (1 - om)  # :146
     sun = diffuse * fsun[:, :, None] + direct
     shade = diffuse * fsha[:, :, None]
     I_dr = swb[:, None, :] * tbcum[:, :, None]  # :151

@@ -236,3 +236,65 @@ def test_grid_mean_of_the_column_partition_world2():
         np.testing.assert_allclose(g["reflectance"], tot[:, 1] / tot[:, 0], rtol=1e-12)
     for k in got[0][1]:
         np.testing.assert_array_equal(got[0][1][k], got[1][1][k])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# more ranks than the round-end box can give: the band partition on 3 / 5 / 8 gloo ranks
+NB_EVEN = 40
+
+
+def _problem_even():
+    from crt1d_amd import spectra, synth
+
+    d = synth.make_columns(5, NB_EVEN, 10, seed=33, uniform_dlai=False)
+    return d, torch.from_numpy(spectra.band_weights(d["wle"]))
+
+
+def _wide_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from crt1d_amd.dist import BandShardPlan
+
+        d, bw = _problem_even()
+        solve_fn, epi = _oracle_fns()
+        plan = BandShardPlan("zq", HostCols(d), HostBands(d), bw, column_tiles=2, solve_fn=solve_fn, epilogue_fn=epi)
+        plan()   # ... and again WITHOUT wait(): the pending all-reduces of the first step are completed before their message buffers are
+        plan()   # rewritten (re-entry guard), so the second step's result is still the full integral
+        r = plan.wait()
+        q.put((rank, plan.band_range, {k: r[k].numpy().copy() for k in ("aI", "aI_sl", "aI_sh", "totals", "reflectance")}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3, 5, 8])
+def test_band_partition_even_shards_world_3_5_8(world):
+    """An even band count is dealt in PAIRS (band_block_range: every shard even, so every rank runs the 16-byte fused flush), the shards
+    tile the spectrum without gap or overlap, and the all-reduced sums reproduce the unsharded ones at 1e-12 on 3, 5 and 8 ranks."""
+    from crt1d_amd.dist import band_block_range, solve_sharded
+
+    ranges = [band_block_range(NB_EVEN, r, world) for r in range(world)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == NB_EVEN
+    assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+    assert all((hi - lo) % 2 == 0 and hi > lo for lo, hi in ranges)
+    assert max(hi - lo for lo, hi in ranges) - min(hi - lo for lo, hi in ranges) <= 2
+    # 300 bands on 8 ranks: 38 x 6 + 36 x 2 (the configuration of BASELINE configs[3])
+    r300 = [band_block_range(300, r, 8) for r in range(8)]
+    assert sorted(hi - lo for lo, hi in r300) == [36, 36, 38, 38, 38, 38, 38, 38]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wide_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d, bw = _problem_even()
+    solve_fn, epi = _oracle_fns()
+    ref = solve_sharded("zq", HostCols(d), HostBands(d), bw, partition="column", solve_fn=solve_fn, epilogue_fn=epi)
+    for rank, band_range, res in got:
+        assert band_range == ranges[rank]
+        for k, v in res.items():
+            np.testing.assert_allclose(v, ref[k].numpy(), rtol=1e-12, atol=1e-13)

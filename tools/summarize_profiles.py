@@ -44,7 +44,7 @@ def main(root):
             if line:
                 b = json.loads(line[0])
                 if "roofline" in b:
-                    e["bench"] = {k: b["roofline"].get(k) for k in ("kernel", "kernel_ms_avg", "achieved", "frac", "algorithmic_bytes_per_launch", "launch_shape", "frac_of_measured_fill")}
+                    e["bench"] = {k: b["roofline"].get(k) for k in ("kernel", "kernel_ms_avg", "achieved", "frac", "algorithmic_bytes_per_launch", "launch_shape", "frac_of_measured_store_set")}
                     e["bench"]["ms_per_step"] = b["ms_per_step"]
                 else:
                     e["bench"] = b
