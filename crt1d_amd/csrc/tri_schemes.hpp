@@ -38,7 +38,7 @@ __device__ inline TriBand load_tri_band(const SolveArgs& a, int c, int b) {
 // and the chain is re-seeded from its own normalised pair every RENORM-th level (tri_advance / tri_step below): (p, q, g) shrink or grow
 // by a bounded factor per level, so nothing over- or underflows in between, and because the schedule depends on the level index only --
 // and every checkpoint spacing M in use is a multiple of RENORM -- a recomputation that starts from a checkpoint's (e, 1, f) repeats the
-// forward sweep's operations exactly: every kernel family produces the same bits.  (RENORM = 0: the state IS the pair; n79.)
+// forward sweep's operations exactly: every kernel family produces the same bits.  (RENORM = 0 would mean "the state is the pair itself"; both schemes are projective now.)
 template <class S>
 __device__ __forceinline__ void tri_advance(const S& st, int k, const double* rec, int nz, typename S::St& s) {
   st.advance(k, rec, nz, s);
@@ -88,20 +88,21 @@ __device__ __forceinline__ void tri_step(const S& st, int k, const double* rec, 
 // ------------------------------------------------------------------------------------------
 // n79 (crt1d/solvers/_solve_n79.py:70-155).  Even row k <-> upward flux at level k, k = 0 .. nz-1.
 struct TriN79 {
+  // state of the forward sweep: e = p / q, f = g / q (see the note above tri_advance)
   struct St {
-    double e, f;
+    double p, q, g;
   };
-  static constexpr int RENORM = 0;
+  static constexpr int RENORM = 4;
   __device__ static inline void pair(const St& s, double& e, double& f) {
-    e = s.e;
-    f = s.f;
+    const double iq = fast_rcp(s.q);
+    e = s.p * iq;
+    f = s.g * iq;
   }
   __device__ static inline void seed(St& s, double e, double f) {
-    s.e = e;
-    s.f = f;
+    s.p = e;
+    s.q = 1.0;
+    s.g = f;
   }
-  __device__ inline void first(const double* rec, int nz, St& s) const { first(rec, nz, s.e, s.f); }
-  __device__ inline void advance(int k, const double* rec, int nz, St& s) const { advance(k, rec, nz, s.e, s.f); }
   static constexpr const char* NAME = "n79";
   static constexpr int NST = 4;   // staged: dn, up, aI_lsl, aI_lsh
   static constexpr int NOUT = 6;  // I_dr, I_df_d, I_df_u, F, aI_lsl, aI_lsh
@@ -139,15 +140,18 @@ struct TriN79 {
     r = trand * (irho * rec[REC_HDR + 6 * nz + j]);
     s = __builtin_fma(-trand, r, refld);
   }
-  __device__ inline void first(const double* rec, int nz, double& e, double& f) const {
-    e = -alb;  // row 0: soil, upward (:79-82)
-    f = swb * rec[REC_HDR] * alb;
+  __device__ inline void first(const double* rec, int nz, St& st) const {
+    st.p = -alb;  // row 0: soil, upward (:79-82)
+    st.q = 1.0;
+    st.g = swb * rec[REC_HDR] * alb;
   }
   // even pair of level k -> even pair of level k+1: the odd row of level k (layer m) and the even row of level k+1
-  // (layer k) of the Thomas sweep (:180-192 applied to rows :85-129), merged into one rational update so that a
-  // single reciprocal is needed:   A = 1 + s_m e,  D = A - r_k r_m,
-  //   e' = -s_k A / D,   f' = (d_even A + r_k (d_odd + s_m f)) / D.     (|r r| >> |A|: no cancellation in D)
-  __device__ inline void advance(int k, const double* rec, int nz, double& e, double& f) const {
+  // (layer k) of the Thomas sweep (:180-192 applied to rows :85-129), merged into one rational update
+  //   A = 1 + s_m e,  D = A - r_k r_m,   e' = -s_k A / D,   f' = (d_even A + r_k (d_odd + s_m f)) / D     (|r r| >> |A|: no cancellation in D)
+  // and multiplied through by q (e = p / q, f = g / q), which takes the division off the chain:   t = q + s_m p  (= A q),
+  //   p' = -s_k t,   q' = t - r_k r_m q,   g' = d_even t + r_k (d_odd q + s_m g).
+  // |q| grows by about r r per level (r = trand / refld, 1e2..1e3 for thin layers): re-seeded every RENORM = 4 levels, far inside the range.
+  __device__ inline void advance(int k, const double* rec, int nz, St& st) const {
     const double* tbcum = rec + REC_HDR;
     const double* omtb = tbcum + nz;
     const int mk = k == 0 ? 1 : k;  // the first downward row uses layer index 1 (:85-92), as the reference
@@ -162,10 +166,10 @@ struct TriN79 {
     const double src = swb * tbcum[k + 1];
     const double d_odd = (src * omtb[mk]) * __builtin_fma(-rho, rm, tau);   // (:92, :119)
     const double d_even = (src * omtb[k]) * __builtin_fma(-tau, r, rho);    // (:109, :129)
-    const double A = __builtin_fma(sm, e, 1.0);
-    const double iD = fast_rcp(__builtin_fma(-r, rm, A));
-    e = -s * A * iD;
-    f = __builtin_fma(d_even, A, r * __builtin_fma(sm, f, d_odd)) * iD;
+    const double t = __builtin_fma(sm, st.p, st.q);
+    st.g = __builtin_fma(d_even, t, r * __builtin_fma(sm, st.g, d_odd * st.q));
+    st.p = -s * t;
+    st.q = __builtin_fma(-(r * rm), st.q, t);
   }
   // top even row (k = nz-1): dn = sky diffuse (:132-135); emits output level nz-1 (no layer above it)
   __device__ inline void top(const double* rec, int nz, double e, double f, double (&o)[NST]) {
@@ -210,6 +214,8 @@ struct TriN79 {
   }
   static constexpr bool derived(int arr) { return arr == 0 || arr == 3; }
   static constexpr int staged_slot(int arr) { return arr == 1 ? 0 : arr == 2 ? 1 : arr == 4 ? 2 : 3; }
+  // staged slots [lo, hi) that the output arrays of a flush class read (class 0: the nz-row arrays, class 1: the nz-1-row arrays)
+  static constexpr int park_slots(int cls, int hi) { return cls == 0 ? (hi ? 2 : 0) : (hi ? 4 : 2); }
   // all outputs of one (level j, band pair) from the staged pairs st[]; same expressions as value<>()
   __device__ static inline void emit(const double* rec, int nz, int j, d2 bc, double invmu_, const d2 (&st)[NST], d2 (&o)[NOUT]) {
     const d2 idr = bc * rec[REC_HDR + j];
@@ -229,8 +235,6 @@ struct TriN79 {
 struct TriN79U : TriN79 {
   double r, s, rr, k_odd, k_even, omtb;        // advance
   double refld, k_dn, k_src, itrand, omt_oma;  // back
-  __device__ inline void first(const double* rec, int nz, St& st) const { TriN79::first(rec, nz, st.e, st.f); }
-  __device__ inline void advance(int k, const double* rec, int nz, St& st) const { advance(k, rec, nz, st.e, st.f); }
   template <typename TIO>
   __device__ inline void init(const double* rec, const SolveArgs& a, int c, int b) {
     init_band(rec, a, load_tri_band<TIO>(a, c, b));
@@ -251,12 +255,12 @@ struct TriN79U : TriN79 {
     k_src = omtb * __builtin_fma(rho, refld, -(tau * trand));
     omt_oma = omt * oma;
   }
-  __device__ inline void advance(int k, const double* rec, int nz, double& e, double& f) const {
+  __device__ inline void advance(int k, const double* rec, int nz, St& st) const {  // (the projective update of TriN79::advance)
     const double src = swb * rec[REC_HDR + k + 1];
-    const double A = __builtin_fma(s, e, 1.0);
-    const double iD = fast_rcp(A - rr);
-    e = -s * A * iD;
-    f = __builtin_fma(src * k_even, A, r * __builtin_fma(s, f, src * k_odd)) * iD;
+    const double t = __builtin_fma(s, st.p, st.q);
+    st.g = __builtin_fma(src * k_even, t, r * __builtin_fma(s, st.g, (src * k_odd) * st.q));
+    st.p = -s * t;
+    st.q = __builtin_fma(-rr, st.q, t);
   }
   __device__ inline void back(int k, const double* rec, int nz, double e, double f, double (&o)[NST]) {
     const double src = swb * rec[REC_HDR + k + 1];
@@ -398,6 +402,7 @@ struct TriZq {
   }
   static constexpr bool derived(int arr) { return arr == 0 || arr == 3 || arr == 6; }
   static constexpr int staged_slot(int arr) { return arr == 1 ? 0 : arr == 2 ? 1 : arr == 4 ? 2 : 3; }
+  static constexpr int park_slots(int, int hi) { return hi ? NST : 0; }  // one flush class, all staged arrays
   __device__ static inline void emit(const double* rec, int nz, int j, d2 bc, double invmu_, const d2 (&st)[NST], d2 (&o)[NOUT]) {
     const d2 S = bc * rec[REC_HDR + j];
     o[0] = S;

@@ -178,6 +178,126 @@ __device__ inline void flush_flat_class(const SolveArgs& a, const double* rec, c
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// WHOLE-LINE flat flush (round 3; pipelines only: the tiles of a column are flushed top-down by the same store waves).  A tile of T rows
+// of an odd spectrum begins and ends inside 128-B lines; flush_flat_class writes those two part-lines per array and tile with plain stores
+// and leaves the merging to L2.  Here the run of a tile is shifted instead: the elements in front of the first line boundary (the head,
+// <= LINE - 1 elements of the tile's lowest row) are not written but PARKED -- their staged values copied to a small LDS area -- and the
+// tile below, whose run ends where this one began, appends them to its own elements.  Every tile then writes whole lines only, all of
+// them streamed; only the first line of a column's bottom tile and the last line of its top tile can be partial (shared with the
+// neighbouring columns, which other workgroups write).  Same value<>() expressions as flush_flat_class -> same bits.
+// Requires line-aligned array bases (flat_flush_ok == 2) and nb >= LINE (a tile is at least one line long).
+// park_in: [NST][LINE] staged values parked by the tile above (row j0 + nr, bands 0 ..); park_out: where this tile parks its own head.
+template <class S, typename TIO, int CLS>
+__device__ inline void flush_flat_class_wl(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride,
+                                           int c, int j0, int T, double invmu, int tid, int nthr, const double* park_in, double* park_out) {
+  typedef TIO vt __attribute__((ext_vector_type(2)));
+  constexpr int LINE = 128 / (int)sizeof(TIO);
+  const int nb = a.nb, nz = a.nz, rows = nz - CLS;
+  const int nr = min(j0 + T, rows) - j0;
+  if (nr <= 0) return;
+  const int n = nr * nb;
+  const long long g0 = ((long long)c * rows + j0) * nb;
+  const bool first = j0 + nr >= rows;  // holds the top row of the class: nothing was parked above it
+  const bool last = j0 == 0;           // bottom tile: its head is written (the line in front belongs to the previous column)
+  const int e_lo = last ? 0 : (int)((LINE - (g0 & (LINE - 1))) & (LINE - 1));                  // own elements [0, e_lo) are parked
+  const int npin = first ? 0 : (int)((LINE - ((g0 + n) & (LINE - 1))) & (LINE - 1));           // parked elements appended behind element n - 1
+  const int mis = (int)((g0 + e_lo) & 1);  // (non-zero in the bottom tile only)
+  const int e0 = e_lo + mis;
+  const int npair = (n - e0) >> 1;
+  const int odd = (n - e0) & 1;
+  const int goff = (int)(g0 & (LINE - 1)), run_hi = n + npin;  // (lines in element offsets from g0: 32-bit arithmetic)
+  const int step = 2 * nthr;
+  int e = e0 + 2 * tid;
+  int t = (int)(((float)e + 0.5f) * (1.0f / (float)nb));
+  int b = e - t * nb;
+  if (b < 0) { --t; b += nb; }
+  if (b >= nb) { ++t; b -= nb; }
+  const int dt = step / nb, db = step - dt * nb;
+  for (int i = tid; i < npair; i += nthr) {
+    const bool wrap = b + 1 >= nb;
+    const int t2 = wrap ? t + 1 : t, b2 = wrap ? 0 : b + 1;
+    const double bcx = bandc[b], bcy = bandc[b2];
+    const int l0 = ((goff + e) & ~(LINE - 1)) - goff;
+    const bool whole = l0 >= e_lo && l0 + LINE <= run_hi;  // false in the first line of a column / the last line of its top tile only
+    for_class<S, TIO, CLS, 0>(nz, [&](auto arr) {
+      constexpr int ARRI = decltype(arr)::value;
+      vt v;
+      v.x = (TIO)S::template value<ARRI>(rec, nz, j0 + t, bcx, invmu, tile, tstride, e);
+      v.y = (TIO)S::template value<ARRI>(rec, nz, j0 + t2, bcy, invmu, tile, tstride, e + 1);
+      vt* dst = reinterpret_cast<vt*>(outp<TIO>(a.o[ARRI]) + g0 + e);
+      if (whole)
+        __builtin_nontemporal_store(v, dst);
+      else
+        *dst = v;
+    });
+    e += step;
+    b += db;
+    t += dt;
+    if (b >= nb) {
+      b -= nb;
+      ++t;
+    }
+  }
+  // behind the pairs: the tile's last element when their count is odd, then the parked elements of the row above -- an even number in
+  // all (the run ends on a line boundary) unless this is the top tile, whose single last element closes the column
+  const int ntail = odd + npin;
+  if (2 * tid < ntail) {
+    const int k = 2 * tid;  // first tail element of this thread
+    auto val = [&](auto arr, int kk) -> double {
+      constexpr int ARRI = decltype(arr)::value;
+      const int ei = n - odd + kk;
+      if (ei < n) return S::template value<ARRI>(rec, nz, j0 + nr - 1, bandc[nb - 1], invmu, tile, tstride, ei);
+      return S::template value<ARRI>(rec, nz, j0 + nr, bandc[ei - n], invmu, park_in, LINE, ei - n);
+    };
+    const long long gi = g0 + n - odd + k;
+    for_class<S, TIO, CLS, 0>(nz, [&](auto arr) {
+      constexpr int ARRI = decltype(arr)::value;
+      if (k + 1 < ntail) {
+        vt v;
+        v.x = (TIO)val(arr, k);
+        v.y = (TIO)val(arr, k + 1);
+        vt* dst = reinterpret_cast<vt*>(outp<TIO>(a.o[ARRI]) + gi);
+        if (!first)
+          __builtin_nontemporal_store(v, dst);  // (completes the run's last line)
+        else
+          *dst = v;
+      } else {
+        outp<TIO>(a.o[ARRI])[gi] = (TIO)val(arr, k);
+      }
+    });
+  }
+  if (tid == nthr - 1 && mis)  // bottom tile starting on an odd element
+    for_class<S, TIO, CLS, 0>(nz, [&](auto arr) {
+      constexpr int ARRI = decltype(arr)::value;
+      outp<TIO>(a.o[ARRI])[g0] = (TIO)S::template value<ARRI>(rec, nz, j0, bandc[0], invmu, tile, tstride, 0);
+    });
+  // park the head for the tile below: the staged arrays this class's outputs are formed from (the classes share one [NST][LINE] block:
+  // n79's level arrays read slots 0, 1 and its layer arrays slots 2, 3 -- S::park_slots)
+  constexpr int QLO = S::park_slots(CLS, 0), QN = S::park_slots(CLS, 1) - QLO;
+  if (tid < e_lo) {  // (e_lo < LINE <= the threads of one store wave)
+#pragma unroll
+    for (int q = QLO; q < QLO + QN; ++q) park_out[q * LINE + tid] = tile[q * tstride + tid];
+  }
+}
+
+template <class S>
+constexpr int flush_classes() { return S::out_rows(S::NOUT - 1, 8) != 8 ? 2 : 1; }
+// doubles of LDS the whole-line flush needs: [2 tiles in flight][NST][LINE]
+template <class S, typename TIO>
+constexpr int park_doubles() { return 2 * S::NST * (128 / (int)sizeof(TIO)); }
+
+template <class S, typename TIO>
+__device__ inline void flush_flat_wl(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride, int c,
+                                     int j0, int T, double invmu, int tid, int nthr, double* park, int pb) {
+  constexpr int LINE = 128 / (int)sizeof(TIO);
+  constexpr int PC = S::NST * LINE;  // one class of one tile
+  double* pin = park + pb * PC;
+  double* pout = park + (pb ^ 1) * PC;
+  flush_flat_class_wl<S, TIO, 0>(a, rec, bandc, tile, tstride, c, j0, T, invmu, tid, nthr, pin, pout);
+  if constexpr (flush_classes<S>() == 2) flush_flat_class_wl<S, TIO, 1>(a, rec, bandc, tile, tstride, c, j0, T, invmu, tid, nthr, pin, pout);
+}
+
 template <class S, typename TIO>
 __device__ inline void flush_flat(const SolveArgs& a, const double* rec, const double* bandc, const double* tile, int tstride, int c,
                                   int j0, int T, double invmu, int tid, int nthr, bool stream) {
@@ -538,7 +658,8 @@ struct PipeCfg {
   int ncomp;     // compute threads (multiple of 64); threads beyond are store threads
   int nck;
   int off_bc, off_ck, off_tile;  // LDS offsets in doubles; tile = [2][NST][T][nb]
-  int flat;  // generic store role: fused flat flush (flush_flat) instead of the per-array generic flush
+  int flat;  // generic store role: fused flat flush (flush_flat) instead of the per-array generic flush; 3 = its whole-line form (flush_flat_wl)
+  int off_park;  // flat == 3: the parked heads, park_doubles() behind the tiles
   // zq_pa with the interpolation fused into the store waves (tri_zqpa.hip): the caller's level count and output arrays
   int nz_out, off_halo;
   void* out[4];
@@ -743,7 +864,9 @@ __device__ __forceinline__ void tri_pipe_store_generic(const SolveArgs& a, const
       const int k = k0 + i;
       if (k > kend) continue;
       lds_barrier();  // tile `buf` is complete
-      if (cfg.flat)
+      if (cfg.flat == 3)
+        flush_flat_wl<S, TIO>(a, rec, bandc, tile + buf * bstride, tstride, c, k, min(T, kend - k + 1), invmu, sid, nst, lds + cfg.off_park, buf);
+      else if (cfg.flat)
         flush_flat<S, TIO>(a, rec, bandc, tile + buf * bstride, tstride, c, k, min(T, kend - k + 1), invmu, sid, nst, cfg.flat == 2);
       else
         flush_arrays<S, TIO, 0>(a, rec, bandc, tile + buf * bstride, tstride, c, k, min(T, kend - k + 1), invmu, inv_nb, sid, nst);
@@ -858,7 +981,14 @@ int launch_pipe_generic(const SolveArgs& a, hipStream_t s, int nstore_waves) {
   cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
   cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
   cfg.flat = a.tune[13] != 1 ? flat_flush_ok<S, TIO>(a) : 0;
-  const size_t sh = ((size_t)cfg.off_tile + (size_t)2 * S::NST * T * a.nb) * sizeof(double);
+  cfg.off_park = cfg.off_tile + 2 * S::NST * T * a.nb;
+  // Whole lines only -- for schemes whose arrays all have nz rows (zq).  Measured at 3e4 x 107 x 60 (tools/ragged_sweep.py --tune=13:2 /
+  // 13:3, same process): zq 1.797 -> 1.709 ms (0.759 -> 0.798 of the peak), uniform and ragged alike; n79, whose two layer arrays need a
+  // second pass per tile, 1.530 -> 1.507 ms on equal-dLAI columns but 1.60 -> 1.72 ms on ragged ones (stamps: the store role then takes
+  // 3 us per tile against 2 us of arithmetic, profiles/r03/nb107/): n79 keeps the part-line form.  tune key 13: 2 / 3 force either form.
+  const bool wl_default = flush_classes<S>() == 1;
+  if (cfg.flat == 2 && a.nb >= 128 / (int)sizeof(TIO) && (a.tune[13] == 3 || (a.tune[13] == 0 && wl_default))) cfg.flat = 3;
+  const size_t sh = ((size_t)cfg.off_park + (cfg.flat == 3 ? park_doubles<S, TIO>() : 0)) * sizeof(double);
   if (sh > MAX_WG_LDS) return CRT_ERR_UNSUPPORTED;
   auto kern = k_tri_pipe<S, TIO, M, T, 512, -1>;
   if (sh > 64 * 1024 &&
@@ -866,7 +996,7 @@ int launch_pipe_generic(const SolveArgs& a, hipStream_t s, int nstore_waves) {
     return CRT_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, a, cfg);
   if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
-  note_kernel("k_tri_pipe<%s,%s> %s M=%d T=%d store_waves=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", cfg.flat ? "flat-flush" : "generic-flush", M, T,
+  note_kernel("k_tri_pipe<%s,%s> %s M=%d T=%d store_waves=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", cfg.flat == 3 ? "whole-line flat-flush" : cfg.flat ? "flat-flush" : "generic-flush", M, T,
               nstore_waves, sh);  // (only a launch that succeeded is reported)
   return (int)CRT_OK;
 }

@@ -17,7 +17,9 @@ scheme = args[0]
 ncol, nb, nz = (int(x) for x in args[1:4])
 d = synth.make_columns(ncol, nb, nz, seed=1234, uniform_dlai="--ragged" not in sys.argv)
 cols, bands = batched.Columns.from_host(d), batched.Bands.from_host(d)
-plan = batched.Plan(scheme, cols, bands)
+opts = dict(a[2:].split("=", 1) for a in sys.argv[1:] if a.startswith("--") and "=" in a)
+tune = {int(k): int(v) for k, v in (kv.split(":") for kv in opts["tune"].split(","))} if "tune" in opts else {}
+plan = batched.Plan(scheme, cols, bands, tune=tune)
 for _ in range(3):
     plan()
 torch.cuda.synchronize()
