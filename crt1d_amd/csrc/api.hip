@@ -1027,7 +1027,7 @@ static int solve_impl(int scheme, const crt_columns* cols, const crt_bands* band
   {  // crt_options.tune is a measurement aid, but it is part of the ABI: out-of-range values are rejected here, before any launch,
      // instead of reaching the kernel configurations (keys: crt_internal.hpp, SolveArgs::tune)
     static const struct { int key, lo, hi; } range[] = {
-        {0, 0, 160 * 1024}, {1, 0, 64}, {2, 0, 255}, {3, 0, 12}, {4, 0, 32}, {8, 0, 16}, {9, 0, 12}, {10, 0, 7}, {11, 0, 12}, {12, 0, 1024}, {13, 0, 3}};
+        {0, 0, 160 * 1024}, {1, 0, 64}, {2, 0, 255}, {3, 0, 12}, {4, 0, 32}, {8, 0, 16}, {9, 0, 12}, {10, 0, 7}, {11, 0, 12}, {12, 0, 1024}, {13, 0, 3}, {5, 0, 2}, {6, 0, 4}};
     bool known[CRT_NTUNE] = {};
     for (const auto& r : range) {
       known[r.key] = true;

@@ -829,6 +829,93 @@ __global__ __launch_bounds__(MAXT) void k_pipe(SolveArgs a, PipeTileCfg cfg) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_pipe_pack: k_pipe for spectra so narrow that one column leaves most of a compute wave idle (nb <= 32: 12 bands use 12 of 64 lanes).
+// The compute threads (ncw waves) own cpw = 64 ncw / nb consecutive columns, thread -> (column in pack, band) = (tid / nb, tid % nb) -- a
+// column may straddle two waves, nothing in the compute role is wave-level; every lane reads its own column's record (LDS, a few distinct
+// addresses per wave) and decides uniform / ragged for itself (level<2>).  The tile is [buffer][column][array][T x nb]: the
+// T-level run of one (column, array) is contiguous in the output, so the store wave walks (column, 16-B vector) with an incremental
+// index and issues one store per array.  Round 3: 2s at 4e5 x 12 x 60 -- see DESIGN 8a.9.
+struct PackCfg {
+  int ncw;  // compute waves
+  int cpw;  // columns per workgroup = 64 ncw / nb
+  int T;    // levels per tile
+};
+
+template <class S, typename TIO, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_pipe_pack(SolveArgs a, PackCfg cfg) {
+  constexpr int VW = 16 / (int)sizeof(TIO);
+  typedef TIO vt __attribute__((ext_vector_type(VW)));
+  extern __shared__ double lds[];
+  const int nb = a.nb, nz = a.nz, T = cfg.T;
+  const int tid = threadIdx.x;
+  const int cpw = cfg.cpw;
+  const int c0 = blockIdx.x * cpw;
+  const int ncol_here = min(cpw, a.ncol - c0);
+  const int ncomp = 64 * cfg.ncw;
+  const int cl = tid / nb;  // column of the pack
+  const bool active = tid < ncomp && cl < ncol_here;  // (ncol_here <= cpw)
+  const int b = active ? tid - cl * nb : 0;
+  BandIn bin = {};
+  if (tid < ncomp) bin = load_band<TIO>(a, c0 + (active ? cl : 0), b, S::SOIL);
+  {  // the records of consecutive columns are consecutive in the workspace
+    const double* src = a.ws + (long long)c0 * a.reclen;
+    for (int i = tid; i < ncol_here * a.reclen; i += blockDim.x) lds[i] = src[i];
+  }
+  __syncthreads();
+  const int rec_dbl = (cpw * a.reclen + 1) & ~1;
+  TIO* tile = reinterpret_cast<TIO*>(lds + rec_dbl);
+  const int arrrun = T * nb, colrun = S::NARR * arrrun, bufrun = cpw * colrun;
+  if (tid < ncomp) {
+    const double* rec = lds + (active ? cl : 0) * a.reclen;
+    S st;
+    st.init(rec, bin, a);
+    int buf = 0;
+    for (int j0 = 0; j0 < nz; j0 += T) {
+      const int Tc = min(T, nz - j0);
+      TIO* tl = tile + buf * bufrun + (active ? cl : 0) * colrun + b;
+      for (int t = 0; t < Tc; ++t) {
+        double val[S::NARR];
+        st.template level<2>(j0 + t, rec, nz, val);
+        if (active) {
+#pragma unroll
+          for (int k = 0; k < S::NARR; ++k) tl[k * arrrun + t * nb] = (TIO)val[k];
+        }
+      }
+      lds_barrier();  // tile complete: hand it to the store waves
+      buf ^= 1;
+    }
+  } else {
+    const int sid = tid - ncomp, nst = blockDim.x - ncomp;
+    const int nbv = nb / VW, arrv = arrrun / VW;
+    int buf = 0;
+    for (int j0 = 0; j0 < nz; j0 += T) {
+      const int Tc = min(T, nz - j0);
+      lds_barrier();  // tile `buf` is complete
+      const int per = Tc * nbv;  // 16-B vectors of one (column, array) run
+      const int total = ncol_here * per;
+      int c = sid / per, v = sid - c * per;
+      const int dc = nst / per, dv = nst - dc * per;
+      for (int idx = sid; idx < total; idx += nst) {
+        const vt* src = reinterpret_cast<const vt*>(tile + buf * bufrun + c * colrun) + v;
+        const long long go = ((long long)(c0 + c) * nz + j0) * nbv + v;
+        vt x[S::NARR];
+#pragma unroll
+        for (int k = 0; k < S::NARR; ++k) x[k] = src[k * arrv];
+#pragma unroll
+        for (int k = 0; k < S::NARR; ++k) __builtin_nontemporal_store(x[k], reinterpret_cast<vt*>(a.o[k]) + go);
+        v += dv;
+        c += dc;
+        if (v >= per) {
+          v -= per;
+          ++c;
+        }
+      }
+      buf ^= 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 constexpr int MAX_DIRECT_LDS = 64 * 1024;
 // tunables (crt_options.tune, per call): [0] LDS bytes a tile may take per workgroup, [1] force T (0 = automatic),
 // [2] TileCfg.flags (bit0: __syncthreads barriers, bit1: generic instead of fused flush).  Measured on MI355X, 2s at 1e4 x 300 x 60 (tools/ab_tile.py, interleaved rounds):
@@ -852,6 +939,40 @@ int launch_tile(const SolveArgs& a, hipStream_t s, bool& done) {
   if (g_tune[0] <= 0) g_tune[0] = DEFAULT_TILE_LDS;
   const int min_nb = a.tune[12] > 0 ? a.tune[12] : MIN_TILE_NB;
   if (nb < min_nb || nb > 1024) return CRT_OK;
+  // very narrow spectra: several columns per compute wave (tune key 5 = 1 keeps one column per workgroup: A/B)
+  if ((nb <= 32 || a.tune[5] == 2) && nb <= 128 && a.tune[5] != 1) {
+    constexpr int VWp = 16 / (int)sizeof(TIO);
+    bool ok = nb % VWp == 0 && (a.nz * nb) % VWp == 0;
+    for (int i = 0; i < S::NARR && ok; ++i)
+      if (reinterpret_cast<uintptr_t>(a.o[i]) & 15) ok = false;
+    if (ok) {
+      PackCfg pc;
+      pc.ncw = a.tune[6] > 0 ? a.tune[6] : (nb <= 32 ? 1 : 2);
+      if (64 * pc.ncw < nb) pc.ncw = (nb + 63) / 64;
+      pc.cpw = 64 * pc.ncw / nb;
+      const int linep = 128 / (int)sizeof(TIO);
+      const int Tap = linep / gcd(nb, linep);  // levels per line-aligned run
+      int Tp = a.tune[4] > 0 ? a.tune[4] : std::max(4, Tap);
+      if (Tp > a.nz) Tp = a.nz;
+      pc.T = Tp;
+      const int cpw = pc.cpw;
+      const int nswp = a.tune[3] > 0 ? a.tune[3] : 1;
+      const size_t shp = (size_t)((cpw * a.reclen + 1) & ~1) * sizeof(double) + (size_t)2 * cpw * S::NARR * Tp * nb * sizeof(TIO);
+      const int thr = 64 * (pc.ncw + nswp);
+      if (shp <= 160 * 1024 && thr <= 512 && (Tp * nb) % VWp == 0) {
+        auto kern = k_pipe_pack<S, TIO, 512>;
+        if (shp > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp) != hipSuccess)
+          return (int)CRT_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3((a.ncol + cpw - 1) / cpw), dim3(thr), shp, s, a, pc);
+        if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
+        note_kernel("k_pipe_pack<%s,%s> columns=%d compute_waves=%d T=%d store_waves=%d lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32", pc.cpw,
+                    pc.ncw, Tp, nswp, shp);
+        done = true;
+        return (int)CRT_OK;
+      }
+    }
+  }
   const int CB = nb <= 256 ? 256 / nb : 1;
   const int nthr = CB > 1 ? 256 : ((nb + 63) / 64) * 64;
   const int line = 128 / (int)sizeof(TIO);  // elements per 128-B line

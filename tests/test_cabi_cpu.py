@@ -145,5 +145,5 @@ def test_tune_values_are_validated_before_any_launch(lib):
 
     assert call({}) == _lib.CRT_ERR_WORKSPACE
     assert call({8: 16, 9: 4, 11: 2, 10: 3, 13: 1}) == _lib.CRT_ERR_WORKSPACE
-    for bad in ({3: 99}, {4: -1}, {8: 10}, {9: 5}, {10: 8}, {11: 13}, {12: 5000}, {13: 4}, {0: 1 << 20}, {5: 1}, {14: 7}, {2: 256}):
+    for bad in ({3: 99}, {4: -1}, {8: 10}, {9: 5}, {10: 8}, {11: 13}, {12: 5000}, {13: 4}, {0: 1 << 20}, {5: 3}, {7: 1}, {14: 7}, {2: 256}):
         assert call(bad) == _lib.CRT_ERR_BAD_ARG, bad
