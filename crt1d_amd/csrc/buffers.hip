@@ -29,7 +29,7 @@
 // process cannot get at it.  crt_hip_buffer_trim releases the rest.
 // Exploration (allocating and classifying more chunks than the request needs, to find the other classes) is bounded: at most half of
 // the memory that would stay free after the request, at most 96 GB, and it is abandoned for good on a device that still shows ONE class
-// after 32 GB (another GPU model or partition mode: nothing to balance there).  Probes run on a private non-blocking stream, so busy
+// after 80 GB (another GPU model or partition mode: nothing to balance there).  Probes run on a private non-blocking stream, so busy
 // torch streams do not distort their timing; they synchronise the host, so a Plan must be constructed outside stream capture.
 #include <hip/hip_runtime.h>
 
@@ -82,7 +82,7 @@ struct Pool {
   double single_ms = 0.0;  // the pattern into one chunk alone
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipStream_t stream = nullptr;  // private, non-blocking: the probes
-  bool one_class = false;        // exploration found a single class in 32 GB: never explore again on this device
+  bool one_class = false;        // exploration found a single class in 80 GB: never explore again on this device
   long long explored = 0;        // chunks classified by exploration so far (statistics / the rule above)
   // statistics (crt_hip_buffer_stats)
   long long created = 0, released = 0, probes = 0;
@@ -282,7 +282,9 @@ int crt_hip_buffer_alloc_set(int32_t n, const size_t* bytes, void** ptrs) {
   const size_t spare = hard > need * CHUNK ? hard - need * CHUNK : 0;
   const size_t extra = p.one_class ? 0 : std::min<size_t>(spare / 2, 96ull << 30);
   const size_t budget = std::min(hard, need * CHUNK + extra);
-  constexpr long long ONE_CLASS_AFTER = 64;  // chunks (32 GB) classified with a single class seen
+  // chunks (80 GB) classified with a single class seen.  (64 chunks at first: inside the 2-35 GB run lengths of one class that round 2
+  // measured -- one bench process in forty started in such a run, gave up and ran its set at the single-class rate, 0.65 instead of 0.83.)
+  constexpr long long ONE_CLASS_AFTER = 160;
   bool oom = false;
   while (have.size() < need || !balanced()) {
     if ((have.size() + 1) * CHUNK > (have.size() < need ? hard : budget)) {
