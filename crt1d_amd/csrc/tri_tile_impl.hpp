@@ -660,23 +660,27 @@ struct PipeCfg {
   int off_bc, off_ck, off_tile;  // LDS offsets in doubles; tile = [2][NST][T][nb]
   int flat;  // generic store role: fused flat flush (flush_flat) instead of the per-array generic flush; 3 = its whole-line form (flush_flat_wl)
   int off_park;  // flat == 3: the parked heads, park_doubles() behind the tiles
+  int cpw;       // packed form (RS == 3): columns per workgroup, thread -> (column, band) = (tid / nb, tid % nb); tile = [NST][cpw][T][nb]
   // zq_pa with the interpolation fused into the store waves (tri_zqpa.hip): the caller's level count and output arrays
   int nz_out, off_halo;
   void* out[4];
 };
 
-template <class S, typename TIO, int M, int T, int RS, int NSTG = S::NST>
+template <class S, typename TIO, int M, int T, int RS, int NSTG = S::NST, bool PACK = false>
 __device__ __forceinline__ void tri_pipe_compute(const SolveArgs& a, const PipeCfg& cfg, double* lds, const TriBand* band = nullptr) {
   const int nb = a.nb, nz = a.nz;
   const int tid = threadIdx.x, nthr = cfg.ncomp;
-  const int c = blockIdx.x;
-  const double* rec = lds;
-  double* bandc = lds + cfg.off_bc;
+  // PACK (narrow spectra): the compute threads own cfg.cpw consecutive columns, thread -> (column of the pack, band); every lane reads its
+  // own column's record, the tile keeps the columns' T x nb blocks one after the other inside each staged array
+  const int cl = PACK ? tid / nb : 0;
+  const bool active = PACK ? (cl < cfg.cpw && (int)blockIdx.x * cfg.cpw + cl < a.ncol) : tid < nb;
+  const int b = active ? tid - cl * nb : 0;
+  const int c = PACK ? (int)blockIdx.x * cfg.cpw + (active ? cl : 0) : (int)blockIdx.x;
+  const double* rec = PACK ? lds + (active ? cl : 0) * a.reclen : lds;
+  double* bandc = lds + cfg.off_bc + (PACK && active ? cl * nb : 0);
   double* ck = lds + cfg.off_ck + tid;  // [nck][2][ncomp]
-  double* tile = lds + cfg.off_tile;
-  const int tstride = T * nb, bstride = NSTG * tstride;  // NSTG: staged arrays kept in the tile (the first NSTG of NST)
-  const bool active = tid < nb;
-  const int b = active ? tid : 0;
+  double* tile = lds + cfg.off_tile + (PACK && active ? cl * (T * nb) : 0);
+  const int tstride = (PACK ? cfg.cpw : 1) * T * nb, bstride = NSTG * tstride;  // NSTG: staged arrays kept in the tile (the first NSTG of NST)
 #ifdef CRT_STAMP
   // diagnostic build only (tools/stamp_timeline.py --tri): wall_clock64 stamps of compute wave 0, written over the column's own K0 record
   // in the workspace (already staged in LDS; K0 rewrites it) -- never into an output
@@ -843,6 +847,72 @@ __device__ __forceinline__ void tri_pipe_store_rs(const SolveArgs& a, const Pipe
   }
 }
 
+// Packed form of the two-pair register-staged store role (RS == 3; tri_pipe_compute<..., PACK>): the tile holds cfg.cpw columns,
+// [NST][cpw][T][nb]; a store thread's two pairs are fixed (column, row, band pair) triples for the whole kernel; every column has its
+// own record and its own base address in the outputs.  cpw * nb <= 64 and T = 4, so the tile's cpw * T * nb / 2 <= 128 pairs are two
+// per thread of ONE store wave.
+template <class S, typename TIO, int M, int T>
+__device__ __forceinline__ void tri_pack_store(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
+  constexpr int RS = 2;
+  const int nb2 = a.nb >> 1, nz = a.nz, cpw = cfg.cpw;
+  const int c0 = blockIdx.x * cpw;
+  const int ncol_here = min(cpw, a.ncol - c0);
+  const int sid = threadIdx.x - cfg.ncomp, nst = blockDim.x - cfg.ncomp;
+  const d2* bandc2 = reinterpret_cast<const d2*>(lds + cfg.off_bc);
+  const d2* tb = reinterpret_cast<const d2*>(lds + cfg.off_tile);
+  const int K = S::rows(nz);
+  const int per = T * nb2, qstride = cpw * per;  // pairs of one column's tile / between staged arrays
+  int ff[RS], cc[RS], tt[RS], pp[RS];
+#pragma unroll
+  for (int it = 0; it < RS; ++it) {
+    const int f = sid + it * nst;
+    const int c = f / per, r = f - c * per, t = r / nb2;
+    ff[it] = f;
+    cc[it] = c < ncol_here ? c : -1;
+    tt[it] = t;
+    pp[it] = r - t * nb2;
+  }
+  for (int seg = (K - 1) / M; seg >= 0; --seg) {
+    const int k0 = seg * M;
+    const int kend = min(k0 + M - 1, K - 1);
+    for (int i = M - T; i >= 0; i -= T) {
+      const int k = k0 + i;
+      if (k > kend) continue;
+      const int jmax = min(kend, nz - 1);
+      d2 v[RS][S::NST];
+      lds_barrier();  // tile complete
+#pragma unroll
+      for (int it = 0; it < RS; ++it)
+        if (cc[it] >= 0) {
+#pragma unroll
+          for (int q = 0; q < S::NST; ++q) v[it][q] = tb[q * qstride + ff[it]];
+        }
+      lds_barrier();  // values are in registers: the compute wave may overwrite the tile
+#pragma unroll
+      for (int it = 0; it < RS; ++it) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int j = k + tt[it];
+        if (cc[it] >= 0 && j <= jmax) {
+          const double* rec = lds + cc[it] * a.reclen;
+          d2 o[S::NOUT];
+          S::emit(rec, nz, j, bandc2[cc[it] * nb2 + pp[it]], rec[S_INVMU], v[it], o);
+#pragma unroll
+          for (int r = 0; r < S::NOUT; ++r) {
+            const int rows = S::out_rows(r, nz);
+            if (j < rows) {
+              typedef TIO vt __attribute__((ext_vector_type(2)));
+              vt w;
+              w.x = (TIO)o[r].x;
+              w.y = (TIO)o[r].y;
+              store_rows<S, TIO>(reinterpret_cast<vt*>(a.o[r]) + ((long long)(c0 + cc[it]) * rows + j) * nb2 + pp[it], w);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // any nb / alignment: the generic flat flush of k_tri_tile, run by the store waves on the double-buffered tile
 template <class S, typename TIO, int M, int T>
 __device__ __forceinline__ void tri_pipe_store_generic(const SolveArgs& a, const PipeCfg& cfg, double* lds) {
@@ -938,9 +1008,33 @@ __device__ __forceinline__ void tri_pipe_store(const SolveArgs& a, const PipeCfg
 // RS = 2 is the narrow-spectrum form (one compute + one store wave per column, two band pairs staged per store thread): five waves per
 // SIMD, i.e. ten of these two-wave workgroups per CU instead of eight.
 template <class S, typename TIO, int M, int T, int MAXT, int RS>
-__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(RS == 2 ? 5 : 4))) void k_tri_pipe(SolveArgs a, PipeCfg cfg) {
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu((RS == 2 || RS == 3) ? 5 : 4))) void k_tri_pipe(SolveArgs a, PipeCfg cfg) {
   static_assert(M % T == 0, "tile height must divide the checkpoint spacing");
   extern __shared__ double lds[];
+  if constexpr (RS == 3) {  // packed: the records of the workgroup's consecutive columns are consecutive in the workspace
+    const int c0 = blockIdx.x * cfg.cpw;
+    const int nhere = min(cfg.cpw, a.ncol - c0);
+    const double* src = a.ws + (long long)c0 * a.reclen;
+    for (int i = threadIdx.x; i < nhere * a.reclen; i += blockDim.x) lds[i] = src[i];
+    __syncthreads();
+    if ((int)threadIdx.x >= cfg.ncomp) {
+      tri_pack_store<S, TIO, M, T>(a, cfg, lds);
+      return;
+    }
+    typedef typename UniformOf<S>::type SU;
+    if constexpr (!std::is_same<S, SU>::value) {
+      // the uniform-column object only when EVERY column of the pack is uniform (the barriers of the compute role must not diverge); a
+      // mixed pack runs the general object on all of its columns -- K0 fills the per-level vectors of uniform columns too (colpre.hip)
+      bool all_unif = true;
+      for (int i = 0; i < nhere; ++i) all_unif = all_unif && lds[i * a.reclen + S_UNIF] != 0.0;
+      if (all_unif) {
+        tri_pipe_compute<SU, TIO, M, T, 2, S::NST, true>(a, cfg, lds);
+        return;
+      }
+    }
+    tri_pipe_compute<S, TIO, M, T, 2, S::NST, true>(a, cfg, lds);
+    return;
+  }
   {
     const double* src = a.ws + (long long)blockIdx.x * a.reclen;
     for (int i = threadIdx.x; i < a.reclen; i += blockDim.x) lds[i] = src[i];
@@ -1001,6 +1095,36 @@ int launch_pipe_generic(const SolveArgs& a, hipStream_t s, int nstore_waves) {
   return (int)CRT_OK;
 }
 
+// narrow spectra, several columns per workgroup (one compute wave + one store wave)
+template <class S, typename TIO>
+int launch_tri_pack(const SolveArgs& a, hipStream_t s) {
+  constexpr int M = 8, T = 4;
+  {
+    if (a.nb % 2 || a.nb < 2 || a.nb > 32) return CRT_ERR_UNSUPPORTED;
+    for (int i = 0; i < S::NOUT; ++i)
+      if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) return CRT_ERR_UNSUPPORTED;
+    const int K = S::rows(a.nz);
+    PipeCfg cfg{};
+    cfg.ncomp = 64;
+    cfg.cpw = 64 / a.nb;
+    cfg.nck = std::max((K - 1) / M - 1, 0);
+    cfg.off_bc = (cfg.cpw * a.reclen + 1) & ~1;
+    cfg.off_ck = cfg.off_bc + 64;
+    cfg.off_tile = cfg.off_ck + 2 * cfg.nck * 64;
+    const size_t sh = ((size_t)cfg.off_tile + (size_t)S::NST * cfg.cpw * T * a.nb) * sizeof(double);
+    if (sh > MAX_WG_LDS / 2) return CRT_ERR_UNSUPPORTED;
+    auto kern = k_tri_pipe<S, TIO, M, T, 512, 3>;
+    if (sh > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+      return CRT_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((a.ncol + cfg.cpw - 1) / cfg.cpw), dim3(128), sh, s, a, cfg);
+    if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
+    note_kernel("k_tri_pipe<%s,%s> packed columns=%d register-staged(2 pairs) M=%d T=%d store_waves=1 lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32",
+                cfg.cpw, M, T, sh);
+    return (int)CRT_OK;
+  }
+}
+
 template <class S, typename TIO, int M, int T>
 int launch_pipe_mt(const SolveArgs& a, hipStream_t s, int nstore_waves, bool regstage) {
   const int ncomp = ((a.nb + 63) / 64) * 64;
@@ -1054,6 +1178,13 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 10
   done = false;
   const int* g_tri_tune = a.tune + 8;  // this call's overrides (crt_options.tune[8..11])
   if (a.tune[12] > 0) min_nb = a.tune[12];
+  if (a.nb <= 32 && a.tune[5] != 1 && g_tri_tune[0] == 0 && g_tri_tune[2] == 0) {  // several columns per compute wave (tune key 5 = 1: off)
+    const int st = launch_tri_pack<S, TIO>(a, s);
+    if (st != CRT_ERR_UNSUPPORTED) {
+      done = st == CRT_OK;
+      return st;
+    }
+  }
   if (a.nb < min_nb || a.nb > 1024) return CRT_OK;  // narrow spectra: the per-wave kernels fill their lanes better
   const int nthr = ((a.nb + 63) / 64) * 64;
   const int K = S::rows(a.nz);
