@@ -390,3 +390,26 @@ def test_f32_storage_default_case_vs_reference(torch_cuda):
             ref = g5[f"4s_tol1e-11__{k}"] if scheme == "4s" else g[f"{scheme}__{k}"]
             err = rel_profile_err(v[0].double().cpu().numpy(), ref)
             assert err <= 2e-6, (scheme, k, err)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("nb", [2, 4, 12, 16, 30, 32])
+def test_packed_narrow_columns_mixed_uniform_and_ragged(torch_cuda, oracle, scheme, nb):
+    """Spectra up to 32 bands run several columns per compute wave (k_pipe_pack, the packed k_tri_pipe).  Columns with uniform and with
+    ragged dLAI ALTERNATE here, so that every pack mixes them (n79 then runs its general scheme object on the whole pack) and the last
+    workgroup is a partial pack; vs the oracle at the bars of test_hip_vs_oracle_synthetic.  zq_pa has no packed form; same bars."""
+    from crt1d_amd import batched, synth
+
+    ncol, nz = 37, 23
+    du = synth.make_columns(ncol, nb, nz, seed=5, uniform_dlai=True)
+    dr = synth.make_columns(ncol, nb, nz, seed=5, uniform_dlai=False)
+    d = dict(du)
+    d["lai"] = du["lai"].copy()
+    d["lai"][1::2] = dr["lai"][1::2]
+    got = _to_np(batched.solve(scheme, batched.Columns.from_host(d), batched.Bands.from_host(d)))
+    ref = oracle.SOLVERS[scheme](_oracle_cols(oracle, d), **_kw(d, scheme))
+    tol = 1e-9 if scheme in ("2s", "bf") else 1e-11
+    for k, v in got.items():
+        assert np.all(np.isfinite(v)), k
+        t = 3e-10 if (scheme == "n79" and k.startswith("aI")) else tol
+        assert rel_profile_err(v, ref[k]) <= t, (k, rel_profile_err(v, ref[k]))

@@ -34,6 +34,8 @@ CASES=(
 "zq_nb12|wf|$R/bench.py --scheme zq --nb 12 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
 "2s_nb12|wf|$R/bench.py --scheme 2s --nb 12 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
 "zq_nb8_wave|wfsq|$R/bench.py --scheme zq --nb 8 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
+"n79_nb12|wf|$R/bench.py --scheme n79 --nb 12 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
+"4s_nb12|wf|$R/bench.py --scheme 4s --nb 12 --ncol 400000 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-pcie"
 "2s_integrated|wfsq|$R/bench.py --scheme 2s --variant integrated $B"
 "n79_integrated|wfsq|$R/bench.py --scheme n79 --variant integrated $B"
 "zq_integrated|wfsq|$R/bench.py --scheme zq --variant integrated $B"

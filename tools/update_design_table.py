@@ -1,16 +1,19 @@
-"""Regenerate the measurement table of DESIGN.md section 5 from profiles/r02/rocprof/summary.json (rows between the headline row and the
+"""Regenerate the measurement table of DESIGN.md section 5 from profiles/r03/rocprof/summary.json (rows between the headline row and the
 '(Before the streaming stores' note).  usage: python tools/update_design_table.py"""
 import json, os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-s = json.load(open(os.path.join(ROOT, "profiles/r02/rocprof/summary.json")))
+s = json.load(open(os.path.join(ROOT, "profiles/r03/rocprof/summary.json")))
 desc = [
     ("2s", "2s 1e4×300×60 (**headline**)"), ("2s_125k", "2s 125000×300×60 (north-star per-GPU share, 73.5 GB of outputs)"), ("bl", "bl"), ("4s", "4s"), ("g77", "g77"), ("bf", "bf"),
     ("n79", "n79 (plain stores: two of its arrays have nz−1 rows)"), ("n79_nz100", "n79 nz=100 (6000×300×100)"), ("zq", "zq"), ("zq_nz100", "zq nz=100 (6000×300×100)"),
     ("band_cfg4", "zq 25000×300×100 (one column tile of the band-mode bench, config 4)"), ("zq_nb38_nz100", "zq **1e5×38×100** (a rank's shard of config 4)"),
     ("2s_nb38", "2s 2e5×38×60"), ("2s_nb107", "2s 3e4×107×60 (the reference's 107 bands)"), ("n79_nb107", "n79 3e4×107×60"), ("zq_nb107", "zq 3e4×107×60"), ("zq_pa", "zq_pa"),
     ("zq_pa_nz100", "zq_pa nz=100 (6000×300×100)"), ("zq_pa_nb107", "zq_pa 3e4×107×60 (odd nb: flat store role)"), ("zq_pa_nb38", "zq_pa 1e5×38×100"), ("2s_f32", "2s, f32 storage"),
-    ("n79_f32", "n79, f32 storage"), ("zq_nb12", "zq 4e5×12×60 (very narrow: one wave per column)"), ("2s_nb12", "2s 4e5×12×60 (very narrow)"), ("zq_nb8_wave", "zq 4e5×8×60 (nb < 10: several columns per wave)"),
+    ("n79_f32", "n79, f32 storage"), ("zq_nb12", "zq 4e5×12×60 (packed: 5 columns per compute wave)"), ("n79_nb12", "n79 4e5×12×60 (packed)"), ("2s_nb12", "2s 4e5×12×60 (packed)"),
+    ("4s_nb12", "4s 4e5×12×60 (packed)"), ("zq_nb8_wave", "zq 4e5×8×60 (packed: 8 columns per compute wave; `k_tri_wave` in round 2)"),
+    ("2s_ragged", "**ragged ΔLAI** 2s"), ("bl_ragged", "ragged bl"), ("4s_ragged", "ragged 4s"), ("g77_ragged", "ragged g77"), ("bf_ragged", "ragged bf"), ("n79_ragged", "ragged n79"),
+    ("n79_nz100_ragged", "ragged n79 nz=100 (6000×300×100)"), ("zq_ragged", "ragged zq"), ("zq_nz100_ragged", "ragged zq nz=100"), ("zq_pa_ragged", "ragged zq_pa"),
 ]
 rows = []
 for k, d in desc:
