@@ -1100,27 +1100,36 @@ template <class S, typename TIO>
 int launch_tri_pack(const SolveArgs& a, hipStream_t s) {
   constexpr int M = 8, T = 4;
   {
-    if (a.nb % 2 || a.nb < 2 || a.nb > 32) return CRT_ERR_UNSUPPORTED;
+    // up to 32 bands: 64 / nb columns on one compute wave; 33 .. 42 bands (the 36-38-band shards of an 8-rank band partition): three
+    // columns on two compute waves (a column may straddle the waves) -- beyond that a pack fills no more lanes than a column by itself
+    const int ncw = a.tune[6] > 0 ? a.tune[6] : (a.nb <= 32 ? 1 : 2);
+    if (a.nb % 2 || a.nb < 2 || 64 * ncw / a.nb < 2 || (a.nb > 42 && a.tune[6] == 0)) return CRT_ERR_UNSUPPORTED;
     for (int i = 0; i < S::NOUT; ++i)
       if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) return CRT_ERR_UNSUPPORTED;
     const int K = S::rows(a.nz);
     PipeCfg cfg{};
-    cfg.ncomp = 64;
-    cfg.cpw = 64 / a.nb;
+    cfg.ncomp = 64 * ncw;
+    cfg.cpw = cfg.ncomp / a.nb;
+    const int nsw = (cfg.cpw * T * (a.nb / 2) + 127) / 128;  // two pairs per store thread
+    if (cfg.ncomp + 64 * nsw > 512) return CRT_ERR_UNSUPPORTED;
     cfg.nck = std::max((K - 1) / M - 1, 0);
     cfg.off_bc = (cfg.cpw * a.reclen + 1) & ~1;
-    cfg.off_ck = cfg.off_bc + 64;
-    cfg.off_tile = cfg.off_ck + 2 * cfg.nck * 64;
+    cfg.off_ck = cfg.off_bc + cfg.ncomp;
+    cfg.off_tile = cfg.off_ck + 2 * cfg.nck * cfg.ncomp;
     const size_t sh = ((size_t)cfg.off_tile + (size_t)S::NST * cfg.cpw * T * a.nb) * sizeof(double);
     if (sh > MAX_WG_LDS / 2) return CRT_ERR_UNSUPPORTED;
+    // 33 .. 42 bands, measured (tools/ragged_sweep.py --tune=5:1 / 5:0, profiles/r03/narrow/tri_pack_38_bands_ab.txt): n79 1.5e5 x 38 x 60
+    // 0.695 -> 0.775 (ragged 0.63 -> 0.72), but 1e5 x 38 x 100 0.71 -> 0.71 / 0.60 -> 0.57 (55 KB of LDS per pack); zq 1e5 x 38 x 100 0.80 -> 0.83,
+    // 1.5e5 x 38 x 60 0.78 -> 0.78, 36 bands 0.83 -> 0.81: taken for n79 while the pack stays below 40 KB, not for zq
+    if (a.nb > 32 && a.tune[6] == 0 && (std::is_same<S, typename UniformOf<S>::type>::value || sh > 40 * 1024)) return CRT_ERR_UNSUPPORTED;
     auto kern = k_tri_pipe<S, TIO, M, T, 512, 3>;
     if (sh > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
       return CRT_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3((a.ncol + cfg.cpw - 1) / cfg.cpw), dim3(128), sh, s, a, cfg);
+    hipLaunchKernelGGL(kern, dim3((a.ncol + cfg.cpw - 1) / cfg.cpw), dim3(cfg.ncomp + 64 * nsw), sh, s, a, cfg);
     if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
-    note_kernel("k_tri_pipe<%s,%s> packed columns=%d register-staged(2 pairs) M=%d T=%d store_waves=1 lds=%zu", S::NAME, sizeof(TIO) == 8 ? "f64" : "f32",
-                cfg.cpw, M, T, sh);
+    note_kernel("k_tri_pipe<%s,%s> packed columns=%d compute_waves=%d register-staged(2 pairs) M=%d T=%d store_waves=%d lds=%zu", S::NAME,
+                sizeof(TIO) == 8 ? "f64" : "f32", cfg.cpw, ncw, M, T, nsw, sh);
     return (int)CRT_OK;
   }
 }
@@ -1178,7 +1187,7 @@ int launch_scheme(const SolveArgs& a, hipStream_t s, bool& done, int min_nb = 10
   done = false;
   const int* g_tri_tune = a.tune + 8;  // this call's overrides (crt_options.tune[8..11])
   if (a.tune[12] > 0) min_nb = a.tune[12];
-  if (a.nb <= 32 && a.tune[5] != 1 && g_tri_tune[0] == 0 && g_tri_tune[2] == 0) {  // several columns per compute wave (tune key 5 = 1: off)
+  if (a.nb <= 64 && a.tune[5] != 1 && g_tri_tune[0] == 0 && g_tri_tune[2] == 0) {  // several columns per compute wave (tune key 5 = 1: off)
     const int st = launch_tri_pack<S, TIO>(a, s);
     if (st != CRT_ERR_UNSUPPORTED) {
       done = st == CRT_OK;
