@@ -294,6 +294,8 @@ struct TriZq {
   static constexpr int NOUT = 7;  // I_dr, I_df_d, I_df_u, F, I_df_d_ss, I_df_u_ss, F_ss
   double I_dr0, I_df0, rho, fwd, q, q0, cu, cd, invmu;
   double idq;     // 1 / (1 - q^2): dlo = dhi = 1 - q^2 on every interior level -- their two reciprocals per back step become none
+  double ilo1;    // 1 / (1 - q0 q): dlo of the lowest layer.  (dhi of the top layer is 1.)  Written as "interior ? idq : fast_rcp(...)" the
+                  // compiler evaluated the reciprocal at EVERY level and selected afterwards (ISA of k_zqpa_pipe2, round 3)
   double xd, xu;  // SWd0[li], SWu0[li] of the level above
 
   __host__ __device__ static inline int rows(int nz) { return nz + 1; }
@@ -320,6 +322,7 @@ struct TriZq {
     cu = r_psi * (1 - t_psi) * (1 - aL);        // :139
     cd = (1 - t_psi) * (1 - aL) * (1 - r_psi);  // :142
     idq = fast_rcp(__builtin_fma(-q, q, 1.0));
+    ilo1 = fast_rcp(__builtin_fma(-q0, q, 1.0));
   }
   // state of the forward sweep: e = p / q, f = g / q (see the note above tri_advance)
   struct St {
@@ -372,16 +375,12 @@ struct TriZq {
     const double qlo = (li == 1) ? q0 : q;
     const double qhi = (li == m) ? 0.0 : q;
     const double dhi = __builtin_fma(-q, qhi, 1.0);
-    const double dlo = __builtin_fma(-qlo, q, 1.0);
     // SWd0[li-1] from the original row 2li:  dhi x_{2li-1} - qhi fwd x_{2li} - fwd x_{2li+1} = C
-    // (1/dhi and 1/dlo take three values per band; keeping them in registers costs the integrated kernel a wave of
-    // occupancy -- 96 -> 98 VGPRs, 1.19 -> 1.45 ms -- and the profile kernels are store-bound, so they are recomputed)
-    // (the level index is the same for every lane: a scalar branch picks the interior's precomputed reciprocal -- the same value,
-    //  fast_rcp of the same 1 - q^2, as the boundary path would compute)
-    const bool interior = li != 1 && li != m;
-    const double xdl = __builtin_fma(dhi * cd, S, fwd * __builtin_fma(qhi, xu, xd)) * (interior ? idq : fast_rcp(dhi));
+    // (1/dhi and 1/dlo take three values per band -- 1 / (1 - q^2), 1 / (1 - q0 q), 1 -- kept in two registers since round 3)
+    const double rdhi = (li == m) ? 1.0 : idq;  // 1 / dhi: the same bits fast_rcp(dhi) gives (dhi is 1 at the top, 1 - q^2 elsewhere)
+    const double xdl = __builtin_fma(dhi * cd, S, fwd * __builtin_fma(qhi, xu, xd)) * rdhi;
     const double xul = __builtin_fma(-e, xdl, f);  // SWu0[li-1]
-    const double iden = interior ? idq : fast_rcp(dlo);   // multiple-scattering correction, eqs. 24/25 (:180-187)
+    const double iden = (li == 1) ? ilo1 : idq;   // 1 / dlo; multiple-scattering correction, eqs. 24/25 (:180-187)
     o[0] = __builtin_fma(q, xul, xd) * iden;
     o[1] = __builtin_fma(qlo, xd, xul) * iden;
     o[2] = xd;   // I_df_d_ss :197

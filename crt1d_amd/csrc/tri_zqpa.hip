@@ -339,11 +339,49 @@ __device__ __forceinline__ void zqpa_compute(const SolveArgs& g, const PipeCfg& 
     if (k_top + i <= K - 1) tri_step(st, k_top + i - 1, rec, Mg, fs, be[i], bf[i]);
   }
   ZSTAMP();
-  // window of the last three computational rows (k, k + 1, k + 2): dnz[z] = SWd[z + 1], upz[z] = SWu[z]
-  double d0 = 0.0, d1 = 0.0, d2_ = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0;
-  int jn = nzo - 1;  // next output level to emit (they leave from the top)
+  // Window of the last three computational rows (k, k + 1, k + 2): d0 = SWd[k + 1], d1 = SWd[k + 2]; u0 = SWu[k], u1 = SWu[k + 1], u2 = SWu[k + 2].
+  // Output level j with interface index ka (K0: the node above lai[j], 1 <= ka <= Mg) interpolates (:357-362, with the clamps of :310 / :335)
+  //   dn = SWd[ka] + (SWd[max(ka - 1, 1)] - SWd[ka]) w,     up = SWu[min(ka, Mg - 1)] + (SWu[ka - 1] - SWu[min(ka, Mg - 1)]) w
+  // and leaves when row k = ka - 2 is done: then SWd[ka] = d1, SWd[ka - 1] = d0, SWu[ka] = u2, SWu[ka - 1] = u1.  The two clamps are built into
+  // the window instead of being tested per level (round 3: the general per-level selection was 60 % of this role's instructions, most of
+  // them scalar): the first row pushed (k = Mg - 1) also fills u1, so that two steps later u2 reads SWu[Mg - 1] where SWu[Mg] is asked for;
+  // and after row 0 one more shift repeats d0 (SWd[1] where SWd[0] is asked for), at which "row -1" the levels with ka = 1 leave.
+  double d0 = 0.0, d1 = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0;
+  int jn = nzo - 1;        // next output level to emit (they leave from the top)
+  int slot = jn % T;       // its row of the output tile
+  // interface index and weight of level jn, requested as soon as jn is known: the LDS round trip + conversion + readfirstlane overlap with
+  // the next back-substitution step instead of heading every step's "does a level leave here?" test
+  int ka = __builtin_amdgcn_readfirstlane((int)kidx[jn]);
+  double w = wgt[jn];
   int buf = 0;
-  auto pick = [](double x0, double x1, double x2, int i) { return i == 0 ? x0 : i == 1 ? x1 : x2; };
+  // levels that leave behind row k (wave-uniform: the level grid belongs to the column)
+  auto emit_levels = [&](int k) {
+    while (jn >= 0 && ka - 2 >= k) {  // (== k for any valid level grid; ">" cannot wait for a row that is already gone)
+      const double dn = d1 + (d0 - d1) * w;  // :360  (same operations as the store-role interpolation of k_zqpa_pipe: same bits)
+      const double up = u2 + (u1 - u2) * w;  // :361
+      if (active) {
+        double* tl = tile + buf * bstride + slot * nb + b;
+        tl[0] = dn;
+        tl[tstride] = up;
+      }
+      if (slot == 0) {  // output tile complete: hand it to the store waves
+        ZSTAMP();
+        lds_barrier();
+        if constexpr (RS > 0)
+          lds_barrier();
+        else
+          buf ^= 1;
+        ZSTAMP();
+        slot = T;
+      }
+      --slot;
+      --jn;
+      if (jn >= 0) {
+        ka = __builtin_amdgcn_readfirstlane((int)kidx[jn]);
+        w = wgt[jn];
+      }
+    }
+  };
   for (int seg = seg_top; seg >= 0; --seg) {
     const int k0 = seg * M;
     const int kend = min(k0 + M - 1, K - 1);
@@ -375,51 +413,21 @@ __device__ __forceinline__ void zqpa_compute(const SolveArgs& g, const PipeCfg& 
           st.top(rec, Mg, be[i], bf[i], o);  // row Mg: boundary only, no output row
         } else {
           st.back(k, rec, Mg, be[i], bf[i], o);
-          d2_ = d1;
           d1 = d0;
           d0 = o[0];
           u2 = u1;
           u1 = u0;
           u0 = o[1];
-          // every output level whose lowest row is k (wave-uniform: the level grid belongs to the column)
-          while (jn >= 0) {
-            const int ka = __builtin_amdgcn_readfirstlane((int)kidx[jn]);
-            if (max(ka - 2, 0) < k) break;  // (== k for any valid level grid; ">" cannot wait for a row that is already gone)
-            const double w = wgt[jn];
-            double da, db, ua, ub;
-            if (ka >= 2 && ka <= Mg - 1) {  // no clamp in play (every level but those next to the ground and the top): rows k + 1, k | k + 2, k + 1
-              da = d1;
-              db = d0;
-              ua = u2;
-              ub = u1;
-            } else {
-              da = pick(d0, d1, d2_, max(ka, 1) - 1 - k);      // SWd[ka]    (:310 clamp)
-              db = pick(d0, d1, d2_, max(ka - 1, 1) - 1 - k);  // SWd[ka-1]
-              ua = pick(u0, u1, u2, min(ka, Mg - 1) - k);      // SWu[ka]    (:335 clamp)
-              ub = pick(u0, u1, u2, min(ka - 1, Mg - 1) - k);  // SWu[ka-1]
-            }
-            const double dn = da + (db - da) * w;  // :360
-            const double up = ua + (ub - ua) * w;  // :361
-            if (active) {
-              double* tl = tile + buf * bstride + (jn % T) * nb + b;
-              tl[0] = dn;
-              tl[tstride] = up;
-            }
-            if (jn % T == 0) {  // output tile complete: hand it to the store waves
-              ZSTAMP();
-              lds_barrier();
-              if constexpr (RS > 0)
-                lds_barrier();
-              else
-                buf ^= 1;
-              ZSTAMP();
-            }
-            --jn;
-          }
+          if (k == K - 2) u1 = u0;  // (the clamp at the top, see above)
+          emit_levels(k);
         }
       }
     }
   }
+  d1 = d0;  // "row -1": SWd[1] once more (the clamp at the ground); u0 is not read by the interpolation
+  u2 = u1;
+  u1 = u0;
+  emit_levels(-1);
   // every hand-over the store waves count on has happened once jn < 0; a level grid that left levels behind (NaN in lai) still gets
   // its barriers, so that no wave of the workgroup is left waiting
   while (jn >= 0) {
