@@ -273,7 +273,6 @@ __device__ __forceinline__ void zqpa_pipe_store_flat(const SolveArgs& a, const P
 // I_df_u), T of them, and the store role is the plain fused flush of the other tridiagonal schemes (I_dr and F formed while flushing):
 // ZqPaOut below is that role's view of the outputs.  Same expressions as k_zqpa_interp -> the same bits as the two-kernel path.
 struct ZqPaOut {
-  static constexpr const char* NAME = "zq_pa";
   static constexpr int NST = 2;   // staged: I_df_d, I_df_u
   static constexpr int NOUT = 4;  // I_dr, I_df_d, I_df_u, F
   __host__ __device__ static inline int rows(int nz) { return nz; }
