@@ -16,12 +16,17 @@ desc = [
     ("n79_nz100_ragged", "ragged n79 nz=100 (6000×300×100)"), ("zq_ragged", "ragged zq"), ("zq_nz100_ragged", "ragged zq nz=100"), ("zq_pa_ragged", "ragged zq_pa"),
 ]
 rows = []
+# the same bench commands WITHOUT the profiler (tools/bench_cases_noprof.py): HIP-event kernel time -> fraction of the peak
+npp = os.path.join(ROOT, "profiles/r03/bench/noprof_summary.json")
+noprof = json.load(open(npp)) if os.path.exists(npp) else {}
 for k, d in desc:
     if k not in s:
         continue
     e = s[k]
     kern = e["bench"]["kernel"].split(" lds=")[0]
-    rows.append(f"| {d} | `{kern}` | {e['rocprof_avg_ms']:.3f} | {e['rocprof_GBs'] / 1e3:.2f} | {e['rocprof_frac_of_8TBs']:.2f} | {e.get('traffic_over_algorithmic', float('nan')):.3f} |")
+    ev = noprof.get(k, {}).get("frac")
+    evs = f" ({ev:.2f})" if ev else ""
+    rows.append(f"| {d} | `{kern}` | {e['rocprof_avg_ms']:.3f} | {e['rocprof_GBs'] / 1e3:.2f} | {e['rocprof_frac_of_8TBs']:.2f}{evs} | {e.get('traffic_over_algorithmic', float('nan')):.3f} |")
 
 
 def ms(d, sub):
