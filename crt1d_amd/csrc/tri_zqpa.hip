@@ -470,7 +470,7 @@ int launch_zqpa_fused2(const SolveArgs& a, hipStream_t s, int nsw, size_t lds_ca
     if (reinterpret_cast<uintptr_t>(a.o[i]) & (2 * sizeof(TIO) - 1)) return CRT_ERR_UNSUPPORTED;
   const int Mg = zqpa_M(a.nz);
   const int ncomp = ((a.nb + 63) / 64) * 64;
-  if (nsw <= 0) nsw = ncomp <= 64 ? 1 : 3;
+  if (nsw <= 0) nsw = ncomp <= 128 ? 1 : 3;  // (two compute waves: one store wave keeps up, 3e4 x 106 x 60 1.19 -> 1.13 ms)
   if (ncomp + 64 * nsw > 1024) nsw = (1024 - ncomp) / 64;
   if (nsw < 1) return CRT_ERR_UNSUPPORTED;
   if (REGSTAGE && T * (a.nb / 2) > PIPE_RS * 64 * nsw) return CRT_ERR_UNSUPPORTED;
@@ -590,7 +590,9 @@ int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s) {
     // Measured (tools/ragged_sweep.py, round 3; both kernels on the division-free sweep): 1e4 x 300 x 60 1.10 (below) vs 1.11-1.13 ms,
     // 6000 x 300 x 100 1.23 vs 1.12-1.15, 3e4 x 106 x 60 1.23 vs 2.67, 1e5 x 38 x 100 3.00 vs 3.58 -> the new form above 128 bands only.
     // Three workgroups per CU (M = 8 capped at 80 registers, 40 B of scratch) gave 1.19 ms: occupancy is not what binds it.
-    if (g_tri_tune[2] != 5 && (a.nb > 128 || g_tri_tune[2] >= 6 || g_tri_tune[0] == 8)) {
+    // (round 3, after the level emission was rewritten: also 65 .. 128 even bands with ONE store wave -- 3e4 x 106 x 60 1.21 -> 1.13 ms; below
+    //  65 bands the older kernel stays ahead, 1e5 x 38 x 100 3.01 vs 3.15 ms: profiles/r03/zqpa_pipe2_narrow_tune.txt)
+    if (g_tri_tune[2] != 5 && (a.nb > 64 || g_tri_tune[2] >= 6 || g_tri_tune[0] == 8)) {
       constexpr size_t HALF2 = MAX_WG_LDS / 2;
       const int mode = g_tri_tune[2];
       if (g_tri_tune[0] == 8) {  // A/B: short segments (fewer registers: five waves per SIMD, three workgroups per CU)
