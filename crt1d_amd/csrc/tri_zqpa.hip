@@ -285,6 +285,17 @@ struct ZqPaOut {
     o[2] = st[1];
     o[3] = idr * invmu_ + 2 * st[1] + 2 * st[0];  // :412
   }
+  // the same outputs element by element, for the flat flush of odd band counts (same expressions as emit -> same bits)
+  template <int ARR>
+  __device__ static inline double value(const double* rec, int nz, int j, double bc, double invmu_, const double* tile, int stride, int idx) {
+    if constexpr (ARR == 0) return bc * rec[REC_HDR + nz + j];
+    if constexpr (ARR == 1) return tile[idx];
+    if constexpr (ARR == 2) return tile[stride + idx];
+    return bc * rec[REC_HDR + nz + j] * invmu_ + 2 * tile[stride + idx] + 2 * tile[idx];
+  }
+  static constexpr bool derived(int arr) { return arr == 0 || arr == 3; }
+  static constexpr int staged_slot(int arr) { return arr == 1 ? 0 : 1; }
+  static constexpr int park_slots(int, int hi) { return hi ? NST : 0; }
 };
 
 // compute role: the zq system on the computational grid (g.nz = Mg rows + 1), checkpointed like tri_pipe_compute, with the emission of
@@ -455,11 +466,52 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(M <= 8 ? 5
     for (int i = 0; i < 4; ++i) ao.o[i] = cfg.out[i];
     if constexpr (RS > 0)
       tri_pipe_store_rs<ZqPaOut, TIO, M, T, RS>(ao, cfg, lds);
+    else if constexpr (RS < 0)
+      tri_pipe_store_generic<ZqPaOut, TIO, M, T>(ao, cfg, lds);  // odd nb: the flat flush of the other tridiagonal schemes
     else
       tri_pipe_store<ZqPaOut, TIO, M, T>(ao, cfg, lds);
     return;
   }
   zqpa_compute<TIO, M, T, RS>(a, cfg, lds, band);
+}
+
+// odd band counts (the reference's 107): the same compute role, double-buffered tile, flat flush in the store waves (whole lines when the
+// output arrays are line-aligned)
+template <typename TIO, int M, int T>
+int launch_zqpa_generic2(const SolveArgs& a, hipStream_t s, int nsw) {
+  if (a.nb < 65 || a.nb > 256) return CRT_ERR_UNSUPPORTED;
+  SolveArgs ao = a;  // (flat_flush_ok looks at the first ZqPaOut::NOUT output arrays)
+  const int flat = a.tune[13] != 1 ? flat_flush_ok<ZqPaOut, TIO>(ao) : 0;
+  if (!flat) return CRT_ERR_UNSUPPORTED;
+  const int Mg = zqpa_M(a.nz);
+  const int ncomp = ((a.nb + 63) / 64) * 64;
+  if (nsw <= 0) nsw = ncomp <= 128 ? 1 : 2;  // (3e4 x 107 x 60: 1 / 2 / 3 store waves 1.27 / 1.33 / 2.29 ms; the older kernel 1.48)
+  const int nthr = ncomp + 64 * nsw;
+  if (nthr > 512) return CRT_ERR_UNSUPPORTED;
+  SolveArgs g = a;
+  g.nz = Mg;
+  for (int i = 0; i < 7; ++i) g.o[i] = nullptr;
+  PipeCfg cfg{};
+  cfg.ncomp = ncomp;
+  cfg.nck = std::max(Mg / M - 1, 0);
+  cfg.off_bc = (a.reclen + 1) & ~1;
+  cfg.off_ck = cfg.off_bc + ((a.nb + 1) & ~1);
+  cfg.off_tile = cfg.off_ck + 2 * cfg.nck * ncomp;
+  cfg.off_park = cfg.off_tile + 2 * ZqPaOut::NST * T * a.nb;
+  cfg.flat = (flat == 2 && a.nb >= 128 / (int)sizeof(TIO) && a.tune[13] != 2) ? 3 : flat;
+  cfg.nz_out = a.nz;
+  for (int i = 0; i < 4; ++i) cfg.out[i] = a.o[i];
+  const size_t sh = ((size_t)cfg.off_park + (cfg.flat == 3 ? park_doubles<ZqPaOut, TIO>() : 0)) * sizeof(double);
+  if (sh > MAX_WG_LDS / 2) return CRT_ERR_UNSUPPORTED;
+  auto kern = k_zqpa_pipe2<TIO, M, T, 512, -1>;
+  if (sh > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+    return (int)CRT_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(a.ncol), dim3(nthr), sh, s, g, cfg);
+  if (hipGetLastError() != hipSuccess) return (int)CRT_ERR_LAUNCH;
+  note_kernel("k_zqpa_pipe2<%s> %s M=%d T=%d store_waves=%d lds=%zu", sizeof(TIO) == 8 ? "f64" : "f32", cfg.flat == 3 ? "whole-line flat-flush" : "flat-flush", M, T,
+              nsw, sh);
+  return (int)CRT_OK;
 }
 
 // returns CRT_ERR_UNSUPPORTED when the shape does not fit
@@ -608,6 +660,10 @@ int launch_zqpa(const SolveArgs& a, double* scratch, hipStream_t s) {
       }
       if (st == CRT_ERR_UNSUPPORTED && mode != 6) st = launch_zqpa_fused2<double, 16, 4, true>(a, s, nsw);
       if (st == CRT_ERR_UNSUPPORTED && mode != 7) st = launch_zqpa_fused2<double, 16, 4, false>(a, s, nsw);
+      if (st != CRT_ERR_UNSUPPORTED) return st;
+    }
+    if (a.nb % 2 == 1 && g_tri_tune[2] != 5) {  // odd band counts: the new compute role with the flat flush (tune key 10 = 5: the kernel below)
+      st = launch_zqpa_generic2<double, 16, 4>(a, s, nsw);
       if (st != CRT_ERR_UNSUPPORTED) return st;
     }
     // narrow spectra (one compute wave per column): M = 12 needs 92 registers, five waves per SIMD instead of four (1e5 x 38 x 100:
