@@ -109,6 +109,29 @@ def main():
         ms = timed(lambda: blocked(warm), 5, st)
         print(f"whole set as {len(plans)} blocks of {blk}, {('no warm-up', 'inputs read before each block (torch sum)', 'inputs read before each block (plain loads, own kernel)')[warm]}: {ms:.3f} ms  "
               f"frac {bps * big * nb / (ms * 1e-3) / 8e12:.3f}", flush=True)
+    # (2b) the read phase of block b + 1 on a SECOND stream while block b is being solved (ordered by events)
+    if touch is not None:
+        st2 = torch.cuda.Stream()
+        evs = [torch.cuda.Event() for _ in plans]
+
+        def warm(i):
+            for t in plans[i][1]:
+                touch(t.data_ptr(), t.numel() * 8, sink.data_ptr(), st2.cuda_stream)
+            evs[i].record(st2)
+
+        def overlapped():
+            st2.wait_stream(st)
+            warm(0)
+            for i, (pl, rows) in enumerate(plans):
+                st.wait_event(evs[i])
+                if i + 1 < len(plans):
+                    warm(i + 1)
+                pl(st, flags=_lib.FLAG_SKIP_PRECOMPUTE)
+
+        for _ in range(2):
+            ms = timed(overlapped, 5, st)
+            print(f"whole set as {len(plans)} blocks of {blk}, inputs of block b+1 read on a second stream while block b is solved: {ms:.3f} ms  "
+                  f"frac {bps * big * nb / (ms * 1e-3) / 8e12:.3f}", flush=True)
     # (3) every block solved twice in a row: is the second launch of a block (inputs just read by the first) the fast one?
     first, second = [], []
     for _ in range(3):
