@@ -413,3 +413,26 @@ def test_packed_narrow_columns_mixed_uniform_and_ragged(torch_cuda, oracle, sche
         assert np.all(np.isfinite(v)), k
         t = 3e-10 if (scheme == "n79" and k.startswith("aI")) else tol
         assert rel_profile_err(v, ref[k]) <= t, (k, rel_profile_err(v, ref[k]))
+
+
+@pytest.mark.parametrize("scheme", ["n79", "zq", "zq_pa", "2s", "g77"])
+@pytest.mark.parametrize("nb", [12, 107, 300])
+def test_extreme_leaf_optics(torch_cuda, oracle, scheme, nb):
+    """Very dark and very bright leaves in the same spectrum (leaf_r, leaf_t from 1e-6 to 0.49, soil from 1e-4 to 0.9): the projective sweeps of
+    n79 / zq carry (p, q, g) whose growth per level is ~(trand / refld)^2 -- up to 1e14 here -- between re-seedings every 4 levels; the oracle
+    is the plain reference recurrence.  Bars: 1e-9 of the profile maximum (2s: 1e-7, its sigma -> 0 conditioning)."""
+    from crt1d_amd import batched, synth
+
+    ncol, nz = 9, 61
+    d = dict(synth.make_columns(ncol, nb, nz, seed=21, uniform_dlai=False))
+    rng = np.random.default_rng(5)
+    lr = 10.0 ** rng.uniform(-6, np.log10(0.49), (ncol, nb))
+    lt = 10.0 ** rng.uniform(-6, np.log10(0.49), (ncol, nb))
+    d["leaf_r"], d["leaf_t"] = lr, lt
+    d["soil_r"] = 10.0 ** rng.uniform(-4, np.log10(0.9), (ncol, nb))
+    got = _to_np(batched.solve(scheme, batched.Columns.from_host(d), batched.Bands.from_host(d)))
+    ref = oracle.SOLVERS[scheme](_oracle_cols(oracle, d), **_kw(d, scheme))
+    tol = 1e-7 if scheme == "2s" else 1e-9
+    for k, v in got.items():
+        assert np.all(np.isfinite(v)), k
+        assert rel_profile_err(v, ref[k]) <= tol, (k, rel_profile_err(v, ref[k]))
