@@ -87,7 +87,9 @@ struct SolveArgs {
   // [9] T (4 / 8 / 12), [10] kernel family of the tridiagonal kernels (1 no pipeline, 2 double-buffered, 3 register-staged, 4 generic
   // pipeline; zq_pa: 1 two-kernel path, 5 round-2 fused kernel, 6 / 7 double-buffered / register-staged k_zqpa_pipe2), [11] their store
   // waves (<= 12) (tri_tile_impl.hpp, tri_zqpa.hip); [12] smallest nb that takes the tile / pipeline kernels (0 = default);
-  // [13] 1 = no flat fused flush for odd nb (per-array generic flush instead), 2 / 3 = its part-line / whole-line form (0: whole lines for zq, part-lines for n79); [5] 1 = no column packing below 33 bands (k_pipe_pack), [6] its compute waves (<= 4); [7], [14], [15] reserved (zero)
+  // [13] 1 = no flat fused flush for odd nb (per-array generic flush instead), 2 / 3 = its part-line / whole-line form (0: whole lines for
+  // zq and zq_pa, part-lines for n79); [5] column packing of narrow spectra (k_pipe_pack, packed k_tri_pipe): 1 = off, 2 = closed forms also
+  // above 32 bands, [6] compute waves of a pack (<= 4); [7], [14], [15] reserved (zero)
   int tune[CRT_NTUNE];
 };
 
